@@ -1,0 +1,248 @@
+/*
+ * ptrace.h — C ABI of libptrace.so, the MI355X-native replacement for the GPU boundary of
+ * austintheriot/ray-tracer-webgl (the WebGL2 surface used by src/webgl.rs + static/shader.frag).
+ *
+ * Everything here is plain C: POD structs, plain pointers, sizes, int error codes.  No torch /
+ * C++ types cross this boundary, nothing throws or aborts across it.  A Rust `extern "C"` block
+ *  binds these symbols unchanged.
+ *
+ * Reference citations are `path:line` relative to the reference repository root.
+ *
+ * Threading contract (same as the reference, src/lib.rs:66-69): one host thread drives a
+ * pt_ctx at a time; separate contexts (one per GPU) are independent.
+ *
+ * There is NO CPU backend: pt_create fails with PT_ERR_NO_DEVICE when no HIP device exists.
+ */
+#ifndef PTRACE_H
+#define PTRACE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* ---- error codes (returned by every int function; 0 = success) ------------------------------ */
+enum {
+  PT_OK = 0,
+  PT_ERR_INVALID = -1,    /* bad argument (NULL, zero size, spp < 1, max_depth < 1 ...)        */
+  PT_ERR_NO_DEVICE = -2,  /* no HIP device / device index out of range                         */
+  PT_ERR_HIP = -3,        /* a HIP runtime call failed; pt_last_error() has the text           */
+  PT_ERR_NOT_READY = -4,  /* render before pt_set_spheres / pt_set_params                      */
+  PT_ERR_CAPACITY = -5,   /* scene or pass count exceeds what was reserved                     */
+};
+
+/* ---- material types: static/shader.frag:45-47, src/glsl.rs:10-24 ---------------------------- */
+enum {
+  PT_DIFFUSE = 0,
+  PT_METAL = 1,
+  PT_GLASS = 2,
+  PT_EMISSIVE = 3, /* build extension (BASELINE config 4): emits `albedo`, absorbs the path     */
+};
+
+/* ---- background modes ----------------------------------------------------------------------- */
+enum {
+  PT_BG_SKY = 0,   /* static/shader.frag:289-294 white→(0.5,0.7,1.0) gradient                   */
+  PT_BG_BLACK = 1, /* build extension for enclosed scenes                                      */
+};
+
+/*
+ * One sphere, exactly the fields webgl::set_geometry uploads per element of `u_sphere_list`
+ * (src/webgl.rs:225-274; struct Sphere static/shader.frag:55-61).  `is_active` is implied by
+ * the count passed to pt_set_spheres.  `radius` may be negative (src/state.rs:200,213): the
+ * outward normal flips, r*r is unchanged.  48 bytes.
+ */
+typedef struct PtSphere {
+  float center[3];
+  float radius;
+  int32_t type; /* PT_DIFFUSE / PT_METAL / PT_GLASS / PT_EMISSIVE; anything else absorbs      */
+  float albedo[3];
+  float fuzz;
+  float refraction_index;
+  int32_t uuid;
+  int32_t _pad;
+} PtSphere;
+
+/*
+ * The per-frame uniform block: what Uniforms::run_setters uploads (src/webgl.rs:279-593,
+ * :629-633; declarations static/shader.frag:79-102), minus the uniforms no code path reads
+ * (u_aspect_ratio, u_viewport_*, u_focal_length, u_w) and the debug overlay (:100-102, dead:
+ * enable_debugging is 0, src/state.rs:259).
+ */
+typedef struct PtParams {
+  uint32_t width;  /* u_width  */
+  uint32_t height; /* u_height */
+  float time;      /* u_time: per-pass seed offset (static/shader.frag:356)                    */
+  int32_t samples_per_pixel; /* u_samples_per_pixel (per pass)                                 */
+  int32_t max_depth;         /* u_max_depth                                                    */
+  float camera_origin[3];     /* u_camera_origin     */
+  float horizontal[3];        /* u_horizontal        */
+  float vertical[3];          /* u_vertical          */
+  float lower_left_corner[3]; /* u_lower_left_corner */
+  float u[3];                 /* u_u                 */
+  float v[3];                 /* u_v                 */
+  float lens_radius;          /* u_lens_radius       */
+  int32_t render_count;       /* u_render_count      (temporal blend only) */
+  int32_t should_average;     /* u_should_average    (temporal blend only) */
+  float last_frame_weight;    /* u_last_frame_weight (temporal blend only) */
+  /* ---- build extensions ---- */
+  int32_t background_mode; /* PT_BG_* */
+  /*
+   * Row partition for multi-GPU rendering.  This context owns the image rows y (0 = bottom,
+   * static/shader.frag:410) with (y / band_rows) % band_count == band_index; its buffers hold
+   * only those rows, compacted in increasing y.  band_count <= 1 means "all rows".
+   */
+  uint32_t band_rows;
+  uint32_t band_index;
+  uint32_t band_count;
+} PtParams;
+
+/*
+ * Inputs of State::update_pipeline (src/state.rs:319-347) / State::default (:98-125): the
+ * camera-derived members of `State`.  All double, like the reference's Vec3 (src/math.rs:17).
+ */
+typedef struct PtCameraIn {
+  uint32_t width, height;
+  double camera_origin[3];
+  double yaw_degrees;   /* State.yaw   */
+  double pitch_degrees; /* State.pitch */
+  double vup[3];
+  double fov_radians;    /* State.camera_field_of_view */
+  double focus_distance; /* State.focus_distance       */
+  double aperture;       /* State.aperture; lens_radius = aperture / 2 (src/state.rs:102)      */
+} PtCameraIn;
+
+/* Look-at form (Shirley-style), for scenes the yaw/pitch form cannot express conveniently. */
+typedef struct PtLookAtIn {
+  uint32_t width, height;
+  double look_from[3], look_at[3], vup[3];
+  double vfov_radians;
+  double focus_distance;
+  double aperture;
+} PtLookAtIn;
+
+typedef struct PtStats {
+  uint64_t segments;        /* ray segments (hit_world invocations) since the last reset        */
+  uint64_t samples;         /* camera paths started                                             */
+  uint64_t sphere_tests;    /* segments * n_spheres                                             */
+  double render_kernel_ms;  /* sum of the path-tracing kernel's durations (HIP events)          */
+  uint32_t render_launches; /* number of path-tracing kernel launches in that sum               */
+  uint32_t total_spp;       /* samples per pixel accumulated                                    */
+  uint32_t n_spheres;
+  uint32_t local_rows;      /* rows held by this context (row partition)                        */
+} PtStats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* ---- lifetime: replaces setup_program + create_texture x2 + create_framebuffer x2 ------------
+ * (src/webgl.rs:66-80, :82-123, :153-167).  Allocates the fp32 linear accumulation buffer for
+ * a w*h image on HIP device `device` and a stream.  Caller frees with pt_destroy. */
+int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height);
+int pt_destroy(pt_ctx* ctx);
+/* resize path, src/state.rs:364-398: reallocates buffers and clears the accumulation */
+int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height);
+
+/* ---- scene + uniforms ------------------------------------------------------------------------
+ * pt_set_spheres replaces webgl::set_geometry (src/webgl.rs:225-274); n is not capped at 15.
+ * pt_set_params replaces Uniforms::run_setters (src/webgl.rs:629-633). Both copy. */
+int pt_set_spheres(pt_ctx* ctx, const PtSphere* spheres, uint32_t n);
+int pt_set_params(pt_ctx* ctx, const PtParams* params);
+
+/* ---- rendering: replaces webgl::render -> draw (src/webgl.rs:180-205, :169-178) ---------------
+ * pt_render enqueues ONE pass (`samples_per_pixel` samples at seed offset `time`) that adds each
+ * pixel's linear radiance sum into the accumulation buffer.  Asynchronous on the context's
+ * stream; no host synchronisation, no allocation (after pt_reserve_passes).
+ * pt_render_passes enqueues n_passes passes in one launch; pass p uses u_time = time + p. The
+ * result is bit-identical to n_passes pt_render calls with those times. */
+int pt_render(pt_ctx* ctx);
+int pt_render_passes(pt_ctx* ctx, uint32_t n_passes);
+/* Pre-sizes the per-pass workspace so pt_render_passes(n <= max_passes) never allocates. */
+int pt_reserve_passes(pt_ctx* ctx, uint32_t max_passes);
+/* render_count = 0 (src/state.rs:343-346): clears accumulation, spp counter and statistics */
+int pt_reset_accum(pt_ctx* ctx);
+int pt_synchronize(pt_ctx* ctx);
+
+/* ---- read-out: replaces the canvas read (src/dom.rs:126-143) -----------------------------------
+ * Writes local_rows*width RGBA fp32 texels (row 0 = lowest owned row): rgb = accum / total_spp,
+ * then sqrt when gamma != 0 (static/shader.frag:376-380); a = 1.  `out` may be a host or a
+ * device pointer.  Synchronises the stream. */
+int pt_resolve(pt_ctx* ctx, float* rgba_out, int gamma);
+/* Same, clamped and quantised to RGBA8 like the reference framebuffer (src/webgl.rs:109-119). */
+int pt_resolve_rgba8(pt_ctx* ctx, uint8_t* rgba_out, int gamma);
+/* Raw accumulation buffer (local_rows*width float4: r,g,b sums, a = spp): device pointer. */
+int pt_accum_ptr(pt_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* Render into caller-owned device memory (e.g. a torch tensor) instead; NULL restores. */
+int pt_bind_accum(pt_ctx* ctx, void* dev_ptr, size_t bytes);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+
+/* ---- temporal blend of the reference, static/shader.frag:387-404 + src/webgl.rs:186-204 --------
+ * Blends the current resolved, gamma-encoded frame with `prev_rgba8` (the ping-pong texture)
+ * using params.render_count / should_average / last_frame_weight, writes RGBA8 to `out_rgba8`.
+ * Both are device or host pointers to local_rows*width*4 bytes. */
+int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
+
+/* ---- diagnostics ------------------------------------------------------------------------------ */
+int pt_get_stats(pt_ctx* ctx, PtStats* out);
+const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
+int pt_abi_version(void);
+int pt_device_count(void);
+/* Device-side evaluation of single arithmetic building blocks (hash, sin/cos, cbrt, ...) for
+ * parity tests; kinds are listed in ray_tracer_webgl_amd/csrc/pt_kernel_args.h.  in/out are
+ * host pointers, n_in/n_out their lengths in floats, n the number of work items. */
+int pt_probe(pt_ctx* ctx, int kind, const float* in, size_t n_in, float* out, size_t n_out,
+             uint32_t n);
+uint32_t pt_local_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count);
+
+/* ---- host-side camera derivation: State::update_pipeline (src/state.rs:319-347) ----------------
+ * Double precision throughout, narrowed to float at the end like Vec3::to_array
+ * (src/math.rs:107-109).  Fills the camera members + width/height + lens_radius of *out and
+ * leaves the rest of *out untouched. */
+int pt_camera_from_state(const PtCameraIn* in, PtParams* out);
+int pt_camera_look_at(const PtLookAtIn* in, PtParams* out);
+
+/* ---- host-side scene types: src/glsl.rs:27-40 ---------------------------------------------------
+ * The reference keeps spheres in f64 on the host (Vec3 is 3 x f64, src/math.rs:17; radius f64;
+ * fuzz / refraction_index f32) and narrows to f32 only at upload (src/webgl.rs:232-262). */
+typedef struct PtHostSphere {
+  double center[3];
+  double radius;
+  int32_t type;
+  int32_t uuid;
+  double albedo[3];
+  float fuzz;
+  float refraction_index;
+} PtHostSphere;
+
+/* The narrowing webgl::set_geometry performs (src/webgl.rs:225-274, Vec3::to_array
+ * src/math.rs:107-109, `sphere.radius as f32`). */
+int pt_narrow_spheres(const PtHostSphere* in, uint32_t n, PtSphere* out);
+/* glsl::set_sphere_uuids (src/glsl.rs:84-88): uuid = index. */
+int pt_set_sphere_uuids(PtHostSphere* spheres, uint32_t n);
+
+/* ---- the reference's built-in scene: State::default sphere_list (src/state.rs:148-257) ---------
+ * Writes up to cap spheres, returns the scene's sphere count (9). */
+int pt_default_scene(PtHostSphere* out, uint32_t cap);
+/* State::default camera block (src/state.rs:98-125) for a w*h canvas. */
+int pt_default_camera(uint32_t width, uint32_t height, PtCameraIn* out);
+
+/* ---- CPU pick ray: glsl::get_center_hit (src/glsl.rs:213-239) + Sphere::hit (:42-82), f64,
+ * t_min = 0, t_max = inf.  Returns 1 on hit (fills t, hit point, normal, front_face, uuid),
+ * 0 on miss, <0 on error. */
+typedef struct PtCenterHit {
+  double t;
+  double hit_point[3];
+  double normal[3];
+  int32_t front_face;
+  int32_t uuid;
+} PtCenterHit;
+int pt_center_hit(const PtHostSphere* spheres, uint32_t n, const PtCameraIn* cam,
+                  PtCenterHit* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRACE_H */

@@ -1,0 +1,74 @@
+"""Loader for libptrace.so (the C ABI of include/ptrace.h).
+
+The library is built in-tree by `make -C ray_tracer_webgl_amd/csrc` (or
+`__graft_entry__.build()`).  There is deliberately no fallback: if the shared object is missing
+or a symbol is absent, importing users get an ImportError / AttributeError, never a CPU path.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptrace.so")
+
+_lib = None
+
+# every symbol include/ptrace.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_ctx = C.c_void_p
+SIGNATURES = {
+    "pt_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_uint32, C.c_uint32]),
+    "pt_destroy": (C.c_int, [_ctx]),
+    "pt_resize": (C.c_int, [_ctx, C.c_uint32, C.c_uint32]),
+    "pt_set_spheres": (C.c_int, [_ctx, C.POINTER(abi.PtSphere), C.c_uint32]),
+    "pt_set_params": (C.c_int, [_ctx, C.POINTER(abi.PtParams)]),
+    "pt_render": (C.c_int, [_ctx]),
+    "pt_render_passes": (C.c_int, [_ctx, C.c_uint32]),
+    "pt_reserve_passes": (C.c_int, [_ctx, C.c_uint32]),
+    "pt_reset_accum": (C.c_int, [_ctx]),
+    "pt_synchronize": (C.c_int, [_ctx]),
+    "pt_resolve": (C.c_int, [_ctx, _vp, C.c_int]),
+    "pt_resolve_rgba8": (C.c_int, [_ctx, _vp, C.c_int]),
+    "pt_accum_ptr": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "pt_bind_accum": (C.c_int, [_ctx, _vp, C.c_size_t]),
+    "pt_set_stream": (C.c_int, [_ctx, _vp]),
+    "pt_blend_rgba8": (C.c_int, [_ctx, _vp, _vp]),
+    "pt_get_stats": (C.c_int, [_ctx, C.POINTER(abi.PtStats)]),
+    "pt_last_error": (C.c_char_p, [_ctx]),
+    "pt_abi_version": (C.c_int, []),
+    "pt_device_count": (C.c_int, []),
+    "pt_probe": (C.c_int, [_ctx, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.c_uint32]),
+    "pt_local_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_camera_from_state": (C.c_int, [C.POINTER(abi.PtCameraIn), C.POINTER(abi.PtParams)]),
+    "pt_camera_look_at": (C.c_int, [C.POINTER(abi.PtLookAtIn), C.POINTER(abi.PtParams)]),
+    "pt_narrow_spheres": (C.c_int, [C.POINTER(abi.PtHostSphere), C.c_uint32, C.POINTER(abi.PtSphere)]),
+    "pt_set_sphere_uuids": (C.c_int, [C.POINTER(abi.PtHostSphere), C.c_uint32]),
+    "pt_default_scene": (C.c_int, [C.POINTER(abi.PtHostSphere), C.c_uint32]),
+    "pt_default_camera": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(abi.PtCameraIn)]),
+    "pt_center_hit": (
+        C.c_int,
+        [C.POINTER(abi.PtHostSphere), C.c_uint32, C.POINTER(abi.PtCameraIn), C.POINTER(abi.PtCenterHit)],
+    ),
+}
+
+
+def load():
+    """Return the ctypes handle of libptrace.so with every signature declared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libptrace.so not found at %s — build it with `make -C ray_tracer_webgl_amd/csrc` "
+            "(there is no CPU fallback)" % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pt_abi_version() != abi.PT_ABI_VERSION:
+        raise ImportError("libptrace.so ABI %d != expected %d" % (lib.pt_abi_version(), abi.PT_ABI_VERSION))
+    _lib = lib
+    return lib

@@ -1,0 +1,541 @@
+// pt_api.hip — the device-facing entry points of include/ptrace.h: context lifetime, scene and
+// uniform upload, kernel launches, read-out, statistics.  Replaces the WebGL2 surface used by
+// src/webgl.rs (setup_program :66, create_texture :82, create_framebuffer :153, set_geometry
+// :225, Uniforms::run_setters :629, render :180 / draw :169) with HIP on gfx950.
+//
+// Rules kept here: nothing throws across the C ABI; pt_render* never allocates or synchronises
+// (graph-capturable once pt_reserve_passes has sized the workspace); no CPU fallback exists.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrace.h"
+#include "pt_kernel_args.h"
+
+#define PT_API extern "C" __attribute__((visibility("default")))
+
+// single translation unit: the kernels are compiled into this object (no -fgpu-rdc needed)
+#include "pt_kernels.hip"
+
+static thread_local std::string g_create_error;
+
+struct pt_ctx {
+  int device = 0;
+  uint32_t width = 0, height = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr; // own_stream or the caller's
+  // scene
+  float* d_geom = nullptr;
+  PtMatRec* d_mat = nullptr;
+  uint32_t n_spheres = 0, sphere_cap = 0;
+  bool have_spheres = false, have_params = false;
+  PtParams params{};
+  uint32_t local_rows = 0;
+  // accumulation
+  float4* own_accum = nullptr;
+  size_t own_accum_pixels = 0;
+  float4* accum = nullptr; // own_accum or caller-bound
+  size_t accum_pixels = 0;
+  bool accum_bound = false;
+  uint32_t total_spp = 0;
+  // per-pass slabs
+  float4* d_slab = nullptr;
+  size_t slab_pixels = 0; // capacity in pixels (passes * local pixels)
+  uint32_t reserved_passes = 1;
+  // read-out staging
+  float4* d_resolve = nullptr;
+  size_t resolve_pixels = 0;
+  // counters + timing
+  unsigned long long* d_counters = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool
+  size_t events_used = 0;
+  double kernel_ms = 0.0;
+  uint32_t launches = 0;
+  uint64_t samples = 0;
+  // device properties
+  int num_cus = 256;
+  int max_lds = 65536;
+  std::string error;
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->error = buf; else g_create_error = buf;
+  return code;
+}
+
+#define PT_HIP(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail((c), PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+uint32_t count_local_rows(uint32_t height, const PtParams& p) {
+  return pt_local_rows(height, p.band_rows, p.band_index, p.band_count);
+}
+
+int ensure_buffers(pt_ctx* c) {
+  size_t pix = (size_t)c->local_rows * c->width;
+  if (pix == 0) pix = 1;
+  if (!c->accum_bound) {
+    if (c->own_accum_pixels < pix) {
+      if (c->own_accum) PT_HIP(c, hipFree(c->own_accum));
+      c->own_accum = nullptr;
+      PT_HIP(c, hipMalloc(&c->own_accum, pix * sizeof(float4)));
+      c->own_accum_pixels = pix;
+      PT_HIP(c, hipMemsetAsync(c->own_accum, 0, pix * sizeof(float4), c->stream));
+      c->total_spp = 0;
+    }
+    c->accum = c->own_accum;
+    c->accum_pixels = c->own_accum_pixels;
+  }
+  size_t need = pix * (size_t)c->reserved_passes;
+  if (c->slab_pixels < need) {
+    if (c->d_slab) PT_HIP(c, hipFree(c->d_slab));
+    c->d_slab = nullptr;
+    PT_HIP(c, hipMalloc(&c->d_slab, need * sizeof(float4)));
+    c->slab_pixels = need;
+  }
+  if (c->resolve_pixels < pix) {
+    if (c->d_resolve) PT_HIP(c, hipFree(c->d_resolve));
+    c->d_resolve = nullptr;
+    PT_HIP(c, hipMalloc(&c->d_resolve, pix * sizeof(float4)));
+    c->resolve_pixels = pix;
+  }
+  return PT_OK;
+}
+
+int fold_events(pt_ctx* c) {
+  // sum finished event pairs into kernel_ms (requires the stream to be idle)
+  for (size_t i = 0; i < c->events_used; i++) {
+    float ms = 0.f;
+    PT_HIP(c, hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second));
+    c->kernel_ms += (double)ms;
+  }
+  c->events_used = 0;
+  return PT_OK;
+}
+
+inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
+  uint32_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  return g > cap ? cap : g;
+}
+
+} // namespace
+
+PT_API int pt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+PT_API const char* pt_last_error(pt_ctx* ctx) {
+  return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) {
+  if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
+  *out = nullptr;
+  if (width == 0 || height == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: empty image");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, PT_ERR_NO_DEVICE,
+                "pt_create: no HIP device (libptrace has no CPU backend by design)");
+  if (device < 0 || device >= n)
+    return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: device %d out of range (0..%d)", device, n - 1);
+  pt_ctx* c = new (std::nothrow) pt_ctx();
+  if (!c) return fail(nullptr, PT_ERR_INVALID, "pt_create: out of host memory");
+  c->device = device;
+  c->width = width;
+  c->height = height;
+  c->local_rows = height;
+  auto bail = [&](hipError_t e, const char* what) {
+    fail(nullptr, PT_ERR_HIP, "pt_create: %s: %s", what, hipGetErrorString(e));
+    delete c;
+    return PT_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->max_lds = (int)prop.sharedMemPerBlock;
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail(e, "hipStreamCreateWithFlags");
+  c->stream = c->own_stream;
+  if ((e = hipMalloc(&c->d_counters, PT_CTR_COUNT * sizeof(unsigned long long))) != hipSuccess)
+    return bail(e, "hipMalloc(counters)");
+  if ((e = hipMemsetAsync(c->d_counters, 0, PT_CTR_COUNT * sizeof(unsigned long long), c->stream)) != hipSuccess)
+    return bail(e, "hipMemsetAsync(counters)");
+  // allow the trace kernel to use the CU's whole 160 KiB LDS for big sphere lists
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_MAX_SPHERES_LDS * 16);
+  int rc = ensure_buffers(c);
+  if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
+  *out = c;
+  return PT_OK;
+}
+
+PT_API int pt_destroy(pt_ctx* c) {
+  if (!c) return PT_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (c->d_geom) (void)hipFree(c->d_geom);
+  if (c->d_mat) (void)hipFree(c->d_mat);
+  if (c->own_accum) (void)hipFree(c->own_accum);
+  if (c->d_slab) (void)hipFree(c->d_slab);
+  if (c->d_resolve) (void)hipFree(c->d_resolve);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return PT_OK;
+}
+
+PT_API int pt_set_stream(pt_ctx* c, void* hip_stream) {
+  if (!c) return PT_ERR_INVALID;
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  int rc = fold_events(c);
+  if (rc != PT_OK) return rc;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return PT_OK;
+}
+
+PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
+  if (!c || (!s && n)) return fail(c, PT_ERR_INVALID, "pt_set_spheres: NULL argument");
+  if (n > PT_MAX_SPHERES_LDS)
+    return fail(c, PT_ERR_CAPACITY, "pt_set_spheres: %u spheres exceed the LDS-resident list (%u)",
+                n, PT_MAX_SPHERES_LDS);
+  PT_HIP(c, hipSetDevice(c->device));
+  if (n > c->sphere_cap) {
+    if (c->d_geom) PT_HIP(c, hipFree(c->d_geom));
+    if (c->d_mat) PT_HIP(c, hipFree(c->d_mat));
+    c->d_geom = nullptr; c->d_mat = nullptr;
+    PT_HIP(c, hipMalloc(&c->d_geom, (size_t)n * 16));
+    PT_HIP(c, hipMalloc(&c->d_mat, (size_t)n * sizeof(PtMatRec)));
+    c->sphere_cap = n;
+  }
+  // split into the 16-byte geometry record the intersection loop stages into LDS and the 32-byte
+  // shading record read once per closest hit
+  std::vector<float> geom((size_t)n * 4);
+  std::vector<PtMatRec> mat(n);
+  for (uint32_t i = 0; i < n; i++) {
+    geom[4 * i + 0] = s[i].center[0];
+    geom[4 * i + 1] = s[i].center[1];
+    geom[4 * i + 2] = s[i].center[2];
+    geom[4 * i + 3] = s[i].radius;
+    mat[i].albedo[0] = s[i].albedo[0];
+    mat[i].albedo[1] = s[i].albedo[1];
+    mat[i].albedo[2] = s[i].albedo[2];
+    mat[i].fuzz = s[i].fuzz;
+    mat[i].refraction_index = s[i].refraction_index;
+    mat[i].type = s[i].type;
+    mat[i].radius = s[i].radius;
+    mat[i].uuid = s[i].uuid;
+  }
+  if (n) {
+    // the stream may still be reading the previous scene
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, hipMemcpy(c->d_geom, geom.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n * sizeof(PtMatRec), hipMemcpyHostToDevice));
+  }
+  c->n_spheres = n;
+  c->have_spheres = true;
+  return PT_OK;
+}
+
+PT_API int pt_set_params(pt_ctx* c, const PtParams* p) {
+  if (!c || !p) return fail(c, PT_ERR_INVALID, "pt_set_params: NULL argument");
+  if (p->width != c->width || p->height != c->height)
+    return fail(c, PT_ERR_INVALID, "pt_set_params: %ux%u does not match the context's %ux%u (use pt_resize)",
+                p->width, p->height, c->width, c->height);
+  if (p->samples_per_pixel < 1 || p->max_depth < 1)
+    return fail(c, PT_ERR_INVALID, "pt_set_params: samples_per_pixel and max_depth must be >= 1");
+  if (p->band_count > 1 && (p->band_rows == 0 || p->band_index >= p->band_count))
+    return fail(c, PT_ERR_INVALID, "pt_set_params: bad row partition (rows %u index %u count %u)",
+                p->band_rows, p->band_index, p->band_count);
+  PT_HIP(c, hipSetDevice(c->device));
+  uint32_t rows = count_local_rows(c->height, *p);
+  auto eff = [](const PtParams& q, uint32_t k) -> uint32_t {
+    if (q.band_count <= 1 || q.band_rows == 0) return k == 2 ? 1u : 0u;
+    return k == 0 ? q.band_rows : (k == 1 ? q.band_index : q.band_count);
+  };
+  bool repartition = rows != c->local_rows;
+  for (uint32_t k = 0; k < 3; k++) repartition |= eff(*p, k) != eff(c->params, k);
+  c->params = *p;
+  c->have_params = true;
+  if (repartition) {
+    c->local_rows = rows;
+    if (c->accum_bound && (size_t)rows * c->width > c->accum_pixels)
+      return fail(c, PT_ERR_CAPACITY, "pt_set_params: bound accumulation buffer too small");
+    int rc = ensure_buffers(c);
+    if (rc != PT_OK) return rc;
+    // a different set of rows: the accumulated image no longer applies
+    PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
+    c->total_spp = 0;
+  }
+  return PT_OK;
+}
+
+PT_API int pt_resize(pt_ctx* c, uint32_t width, uint32_t height) {
+  if (!c || width == 0 || height == 0) return fail(c, PT_ERR_INVALID, "pt_resize: bad size");
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  c->width = width;
+  c->height = height;
+  c->have_params = false; // uniforms must be re-uploaded for the new size
+  c->params.band_count = 0;
+  c->local_rows = height;
+  if (c->accum_bound) { c->accum_bound = false; c->accum = nullptr; }
+  int rc = ensure_buffers(c);
+  if (rc != PT_OK) return rc;
+  return pt_reset_accum(c);
+}
+
+PT_API int pt_reserve_passes(pt_ctx* c, uint32_t max_passes) {
+  if (!c || max_passes == 0) return fail(c, PT_ERR_INVALID, "pt_reserve_passes: bad argument");
+  PT_HIP(c, hipSetDevice(c->device));
+  if (max_passes > c->reserved_passes) {
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    c->reserved_passes = max_passes;
+  }
+  return ensure_buffers(c);
+}
+
+PT_API int pt_reset_accum(pt_ctx* c) {
+  if (!c) return PT_ERR_INVALID;
+  PT_HIP(c, hipSetDevice(c->device));
+  if (c->accum)
+    PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
+  PT_HIP(c, hipMemsetAsync(c->d_counters, 0, PT_CTR_COUNT * sizeof(unsigned long long), c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  c->events_used = 0;
+  c->kernel_ms = 0.0;
+  c->launches = 0;
+  c->total_spp = 0;
+  c->samples = 0;
+  return PT_OK;
+}
+
+PT_API int pt_bind_accum(pt_ctx* c, void* dev_ptr, size_t bytes) {
+  if (!c) return PT_ERR_INVALID;
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  if (!dev_ptr) {
+    c->accum_bound = false;
+    c->accum = nullptr;
+    int rc = ensure_buffers(c);
+    c->total_spp = 0;
+    return rc;
+  }
+  size_t need = (size_t)c->local_rows * c->width * sizeof(float4);
+  if (bytes < need) return fail(c, PT_ERR_CAPACITY, "pt_bind_accum: %zu bytes < %zu needed", bytes, need);
+  if (((uintptr_t)dev_ptr & 15u) != 0) return fail(c, PT_ERR_INVALID, "pt_bind_accum: pointer not 16-byte aligned");
+  c->accum = (float4*)dev_ptr;
+  c->accum_pixels = bytes / sizeof(float4);
+  c->accum_bound = true;
+  c->total_spp = 0; // the caller owns the contents; spp counting restarts
+  return PT_OK;
+}
+
+PT_API int pt_accum_ptr(pt_ctx* c, void** dev_ptr, size_t* bytes) {
+  if (!c || !dev_ptr) return PT_ERR_INVALID;
+  *dev_ptr = c->accum;
+  if (bytes) *bytes = (size_t)c->local_rows * c->width * sizeof(float4);
+  return PT_OK;
+}
+
+PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
+  if (!c) return PT_ERR_INVALID;
+  if (!c->have_spheres || !c->have_params)
+    return fail(c, PT_ERR_NOT_READY, "pt_render: pt_set_spheres and pt_set_params must come first");
+  if (n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_render_passes: n_passes == 0");
+  if (n_passes > c->reserved_passes)
+    return fail(c, PT_ERR_CAPACITY, "pt_render_passes: %u passes > %u reserved (pt_reserve_passes)",
+                n_passes, c->reserved_passes);
+  if (c->local_rows == 0) return PT_OK; // this band owns no rows
+  PT_HIP(c, hipSetDevice(c->device));
+
+  const PtParams& p = c->params;
+  PtKernelArgs A;
+  memset(&A, 0, sizeof A);
+  for (int k = 0; k < 3; k++) {
+    A.origin[k] = p.camera_origin[k];
+    A.horizontal[k] = p.horizontal[k];
+    A.vertical[k] = p.vertical[k];
+    A.llc[k] = p.lower_left_corner[k];
+    A.cam_u[k] = p.u[k];
+    A.cam_v[k] = p.v[k];
+  }
+  A.lens_radius = p.lens_radius;
+  A.time0 = p.time;
+  A.spp = p.samples_per_pixel;
+  A.max_depth = p.max_depth;
+  A.background_mode = p.background_mode;
+  A.width = c->width;
+  A.height = c->height;
+  A.local_rows = c->local_rows;
+  A.band_rows = p.band_rows ? p.band_rows : 1;
+  A.band_index = p.band_index;
+  A.band_count = p.band_count;
+  A.n_passes = n_passes;
+  A.n_spheres = c->n_spheres;
+  A.tiles_x = (c->width + 7) / 8;
+  A.tiles_y = (c->local_rows + 7) / 8;
+  unsigned long long items = (unsigned long long)A.tiles_x * A.tiles_y * n_passes * 64ull;
+  if (items > 0xfffffff0ull)
+    return fail(c, PT_ERR_CAPACITY, "pt_render_passes: %llu work items exceed 2^32; render fewer passes per call", items);
+  A.n_items = (uint32_t)items;
+  A.geom = c->d_geom;
+  A.mat = c->d_mat;
+  A.slab = reinterpret_cast<float*>(c->d_slab);
+  A.counters = c->d_counters;
+
+  // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
+  // per CU when the staged list takes most of the 160 KiB LDS
+  size_t lds = (size_t)c->n_spheres * 16;
+  uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
+  int per_cu = 0;
+  PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pt_trace_kernel),
+                                                         (int)block, lds));
+  if (per_cu < 1) per_cu = 1;
+  unsigned long long want = (items + block - 1) / block;
+  unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
+  uint32_t grid = (uint32_t)(want < resident ? want : resident);
+  if (grid < 1) grid = 1;
+
+  if (c->events_used == c->events.size()) {
+    if (c->events.size() >= 512) {
+      // pool full: drain (this synchronises, but only once per 512 launches)
+      PT_HIP(c, hipStreamSynchronize(c->stream));
+      int rc = fold_events(c);
+      if (rc != PT_OK) return rc;
+    } else {
+      hipEvent_t a, b;
+      PT_HIP(c, hipEventCreate(&a));
+      PT_HIP(c, hipEventCreate(&b));
+      c->events.emplace_back(a, b);
+    }
+  }
+  auto& ev = c->events[c->events_used++];
+
+  PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  PT_HIP(c, hipEventRecord(ev.first, c->stream));
+  hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
+  PT_HIP(c, hipGetLastError());
+  PT_HIP(c, hipEventRecord(ev.second, c->stream));
+
+  uint32_t n_pix = c->local_rows * c->width;
+  hipLaunchKernelGGL(pt_accumulate_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream,
+                     c->accum, c->d_slab, n_pix, n_passes);
+  PT_HIP(c, hipGetLastError());
+
+  c->launches++;
+  c->total_spp += n_passes * (uint32_t)p.samples_per_pixel;
+  c->samples += (uint64_t)n_pix * n_passes * (uint64_t)p.samples_per_pixel;
+  return PT_OK;
+}
+
+PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
+
+PT_API int pt_synchronize(pt_ctx* c) {
+  if (!c) return PT_ERR_INVALID;
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+static int resolve_common(pt_ctx* c, void* out, int gamma, int mode, const uint8_t* prev) {
+  if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_resolve: NULL argument");
+  if (c->total_spp == 0) return fail(c, PT_ERR_NOT_READY, "pt_resolve: nothing rendered yet");
+  PT_HIP(c, hipSetDevice(c->device));
+  uint32_t n_pix = c->local_rows * c->width;
+  if (n_pix == 0) return PT_OK;
+  float scale = 1.0f / (float)c->total_spp; // static/shader.frag:376
+  uint32_t grid = grid_for(n_pix, 256, 2048);
+  size_t bytes;
+  if (mode == 0) {
+    hipLaunchKernelGGL(pt_resolve_kernel, dim3(grid), dim3(256), 0, c->stream, c->accum, c->d_resolve,
+                       n_pix, scale, gamma);
+    bytes = (size_t)n_pix * sizeof(float4);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL(pt_resolve_rgba8_kernel, dim3(grid), dim3(256), 0, c->stream, c->accum,
+                       reinterpret_cast<uint32_t*>(c->d_resolve), n_pix, scale, gamma);
+    bytes = (size_t)n_pix * 4;
+  } else {
+    // stage prev into the upper half of the resolve buffer (16 B/pixel holds 4 B in + 4 B out)
+    uint32_t* d_out = reinterpret_cast<uint32_t*>(c->d_resolve);
+    uint32_t* d_prev = d_out + n_pix;
+    PT_HIP(c, hipMemcpyAsync(d_prev, prev, (size_t)n_pix * 4, hipMemcpyDefault, c->stream));
+    hipLaunchKernelGGL(pt_blend_rgba8_kernel, dim3(grid), dim3(256), 0, c->stream, c->accum, d_prev, d_out,
+                       n_pix, scale, c->params.render_count, c->params.should_average,
+                       c->params.last_frame_weight);
+    bytes = (size_t)n_pix * 4;
+  }
+  PT_HIP(c, hipGetLastError());
+  PT_HIP(c, hipMemcpyAsync(out, c->d_resolve, bytes, hipMemcpyDefault, c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+PT_API int pt_resolve(pt_ctx* c, float* rgba_out, int gamma) { return resolve_common(c, rgba_out, gamma, 0, nullptr); }
+PT_API int pt_resolve_rgba8(pt_ctx* c, uint8_t* rgba_out, int gamma) { return resolve_common(c, rgba_out, gamma, 1, nullptr); }
+PT_API int pt_blend_rgba8(pt_ctx* c, const uint8_t* prev, uint8_t* out) {
+  if (!prev) return fail(c, PT_ERR_INVALID, "pt_blend_rgba8: prev is NULL");
+  return resolve_common(c, out, 1, 2, prev);
+}
+
+PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
+  if (!c || !out) return PT_ERR_INVALID;
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  int rc = fold_events(c);
+  if (rc != PT_OK) return rc;
+  unsigned long long ctr[PT_CTR_COUNT];
+  PT_HIP(c, hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  out->segments = ctr[PT_CTR_SEGMENTS];
+  out->samples = c->samples;
+  out->sphere_tests = ctr[PT_CTR_SEGMENTS] * (uint64_t)c->n_spheres;
+  out->render_kernel_ms = c->kernel_ms;
+  out->render_launches = c->launches;
+  out->total_spp = c->total_spp;
+  out->n_spheres = c->n_spheres;
+  out->local_rows = c->local_rows;
+  return PT_OK;
+}
+
+// Device-side evaluation of single PT-SPEC functions (parity tests; see pt_kernel_args.h).
+// `in`/`out` are HOST pointers; counts are in floats.
+PT_API int pt_probe(pt_ctx* c, int kind, const float* in, size_t n_in, float* out, size_t n_out,
+                    uint32_t n) {
+  if (!c || !in || !out || n == 0) return fail(c, PT_ERR_INVALID, "pt_probe: bad argument");
+  PT_HIP(c, hipSetDevice(c->device));
+  float *d_in = nullptr, *d_out = nullptr;
+  PT_HIP(c, hipMalloc(&d_in, n_in * sizeof(float)));
+  PT_HIP(c, hipMalloc(&d_out, n_out * sizeof(float)));
+  PT_HIP(c, hipMemcpy(d_in, in, n_in * sizeof(float), hipMemcpyHostToDevice));
+  PT_HIP(c, hipMemset(d_out, 0, n_out * sizeof(float)));
+  hipLaunchKernelGGL(pt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, kind, d_in, d_out, n);
+  PT_HIP(c, hipGetLastError());
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  PT_HIP(c, hipMemcpy(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost));
+  PT_HIP(c, hipFree(d_in));
+  PT_HIP(c, hipFree(d_out));
+  return PT_OK;
+}

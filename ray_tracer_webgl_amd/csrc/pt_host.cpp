@@ -1,0 +1,162 @@
+// pt_host.cpp — the host-only entry points of include/ptrace.h (no HIP calls in this file):
+// camera derivation, the reference's built-in scene, the f32 narrowing, the f64 pick ray.
+#include "pt_host.hpp"
+
+#define PT_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+pt::State state_from_camera_in(const PtCameraIn& in) {
+  pt::State s;
+  s.width = in.width;
+  s.height = in.height;
+  s.camera_origin = pt::Point(in.camera_origin[0], in.camera_origin[1], in.camera_origin[2]);
+  s.yaw = in.yaw_degrees;
+  s.pitch = in.pitch_degrees;
+  s.vup = pt::Vec3(in.vup[0], in.vup[1], in.vup[2]);
+  s.camera_field_of_view = in.fov_radians;
+  s.focus_distance = in.focus_distance;
+  s.aperture = in.aperture;
+  s.lens_radius = in.aperture / 2.0; // src/state.rs:102
+  s.recompute();
+  return s;
+}
+
+void camera_members_to_params(const pt::State& s, PtParams* out) {
+  out->width = s.width;
+  out->height = s.height;
+  pt::put3(out->camera_origin, s.camera_origin);
+  pt::put3(out->horizontal, s.horizontal);
+  pt::put3(out->vertical, s.vertical);
+  pt::put3(out->lower_left_corner, s.lower_left_corner);
+  pt::put3(out->u, s.u);
+  pt::put3(out->v, s.v);
+  out->lens_radius = (float)s.lens_radius;
+}
+
+} // namespace
+
+PT_API int pt_camera_from_state(const PtCameraIn* in, PtParams* out) {
+  if (!in || !out || in->width == 0 || in->height == 0) return PT_ERR_INVALID;
+  pt::State s = state_from_camera_in(*in);
+  camera_members_to_params(s, out);
+  return PT_OK;
+}
+
+// Same pipeline with (look_from, look_at) instead of (origin, yaw, pitch): w = normalize(origin
+// - look_at) is what src/state.rs:330-331 computes from origin + camera_front.
+PT_API int pt_camera_look_at(const PtLookAtIn* in, PtParams* out) {
+  if (!in || !out || in->width == 0 || in->height == 0) return PT_ERR_INVALID;
+  pt::State s;
+  s.width = in->width;
+  s.height = in->height;
+  s.camera_origin = pt::Point(in->look_from[0], in->look_from[1], in->look_from[2]);
+  pt::Point look_at(in->look_at[0], in->look_at[1], in->look_at[2]);
+  s.vup = pt::Vec3(in->vup[0], in->vup[1], in->vup[2]);
+  s.camera_field_of_view = in->vfov_radians;
+  s.focus_distance = in->focus_distance;
+  s.aperture = in->aperture;
+  s.lens_radius = in->aperture / 2.0;
+  s.aspect_ratio = (double)s.width / (double)s.height;
+  double camera_h = std::tan(s.camera_field_of_view / 2.);
+  s.w = pt::normalize(s.camera_origin - look_at);
+  s.u = pt::normalize(pt::cross(s.vup, s.w));
+  s.v = pt::cross(s.w, s.u);
+  s.viewport_height = 2. * camera_h;
+  s.viewport_width = s.viewport_height * s.aspect_ratio;
+  s.horizontal = s.focus_distance * s.viewport_width * s.u;
+  s.vertical = s.focus_distance * s.viewport_height * s.v;
+  s.lower_left_corner =
+      s.camera_origin - s.horizontal / 2. - s.vertical / 2. - s.focus_distance * s.w;
+  camera_members_to_params(s, out);
+  return PT_OK;
+}
+
+PT_API int pt_default_camera(uint32_t width, uint32_t height, PtCameraIn* out) {
+  if (!out || width == 0 || height == 0) return PT_ERR_INVALID;
+  pt::State s = pt::State::default_for(width, height);
+  out->width = width;
+  out->height = height;
+  out->camera_origin[0] = s.camera_origin.x;
+  out->camera_origin[1] = s.camera_origin.y;
+  out->camera_origin[2] = s.camera_origin.z;
+  out->yaw_degrees = s.yaw;
+  out->pitch_degrees = s.pitch;
+  out->vup[0] = s.vup.x; out->vup[1] = s.vup.y; out->vup[2] = s.vup.z;
+  out->fov_radians = s.camera_field_of_view;
+  out->focus_distance = s.focus_distance;
+  out->aperture = s.aperture;
+  return PT_OK;
+}
+
+PT_API int pt_default_scene(PtHostSphere* out, uint32_t cap) {
+  std::vector<pt::Sphere> v = pt::State::default_spheres();
+  pt::set_sphere_uuids(v);
+  if (out) {
+    for (uint32_t i = 0; i < v.size() && i < cap; i++) {
+      const pt::Sphere& s = v[i];
+      PtHostSphere& o = out[i];
+      o.center[0] = s.center.x; o.center[1] = s.center.y; o.center[2] = s.center.z;
+      o.radius = s.radius;
+      o.type = (int32_t)s.material.material_type;
+      o.uuid = s.uuid;
+      o.albedo[0] = s.material.albedo.x; o.albedo[1] = s.material.albedo.y;
+      o.albedo[2] = s.material.albedo.z;
+      o.fuzz = s.material.fuzz;
+      o.refraction_index = s.material.refraction_index;
+    }
+  }
+  return (int)v.size();
+}
+
+static pt::Sphere from_host(const PtHostSphere& h) {
+  pt::Sphere s;
+  s.center = pt::Vec3(h.center[0], h.center[1], h.center[2]);
+  s.radius = h.radius;
+  s.material.material_type = (pt::MaterialType)h.type;
+  s.material.albedo = pt::Vec3(h.albedo[0], h.albedo[1], h.albedo[2]);
+  s.material.fuzz = h.fuzz;
+  s.material.refraction_index = h.refraction_index;
+  s.uuid = h.uuid;
+  return s;
+}
+
+PT_API int pt_narrow_spheres(const PtHostSphere* in, uint32_t n, PtSphere* out) {
+  if ((!in || !out) && n) return PT_ERR_INVALID;
+  for (uint32_t i = 0; i < n; i++) out[i] = pt::narrow(from_host(in[i]));
+  return PT_OK;
+}
+
+PT_API int pt_set_sphere_uuids(PtHostSphere* spheres, uint32_t n) {
+  if (!spheres && n) return PT_ERR_INVALID;
+  for (uint32_t i = 0; i < n; i++) spheres[i].uuid = (int32_t)i;
+  return PT_OK;
+}
+
+PT_API int pt_center_hit(const PtHostSphere* spheres, uint32_t n, const PtCameraIn* cam,
+                         PtCenterHit* out) {
+  if (!cam || !out || (!spheres && n) || cam->width == 0 || cam->height == 0)
+    return PT_ERR_INVALID;
+  pt::State s = state_from_camera_in(*cam);
+  s.sphere_list.reserve(n);
+  for (uint32_t i = 0; i < n; i++) s.sphere_list.push_back(from_host(spheres[i]));
+  pt::HitResultData h;
+  if (!pt::get_center_hit(s, h)) return 0;
+  out->t = h.t;
+  out->hit_point[0] = h.hit_point.x; out->hit_point[1] = h.hit_point.y;
+  out->hit_point[2] = h.hit_point.z;
+  out->normal[0] = h.normal.x; out->normal[1] = h.normal.y; out->normal[2] = h.normal.z;
+  out->front_face = h.front_face ? 1 : 0;
+  out->uuid = h.uuid;
+  return 1;
+}
+
+PT_API uint32_t pt_local_rows(uint32_t height, uint32_t band_rows, uint32_t band_index,
+                              uint32_t band_count) {
+  if (band_count <= 1 || band_rows == 0) return height;
+  uint32_t n = 0;
+  for (uint32_t y = 0; y < height; y++) n += ((y / band_rows) % band_count == band_index);
+  return n;
+}
+
+PT_API int pt_abi_version(void) { return PT_ABI_VERSION; }

@@ -1,0 +1,52 @@
+// pt_kernel_args.h — launch-argument block shared by the host API (pt_api.hip) and the
+// kernels (pt_kernels.hip).  Passed by value; everything in it is wave-uniform (SGPRs).
+#pragma once
+#include <stdint.h>
+
+// Per-sphere shading record, fetched from global memory / L2 only for the closest hit of a
+// segment (the intersection loop itself reads just the 16-byte LDS geometry record).
+struct PtMatRec {
+  float albedo[3];
+  float fuzz;
+  float refraction_index;
+  int32_t type;
+  float radius;  // signed: the outward normal divides by it (static/shader.frag:170)
+  int32_t uuid;
+};
+static_assert(sizeof(PtMatRec) == 32, "PtMatRec must be 32 bytes");
+
+struct PtKernelArgs {
+  // uniform block, static/shader.frag:79-99 (see include/ptrace.h PtParams)
+  float origin[3], horizontal[3], vertical[3], llc[3], cam_u[3], cam_v[3];
+  float lens_radius;
+  float time0;  // pass p renders with u_time = time0 + float(p)
+  int32_t spp;
+  int32_t max_depth;
+  int32_t background_mode;
+  uint32_t width, height;  // full image
+  uint32_t local_rows;     // rows owned by this context
+  uint32_t band_rows, band_index, band_count;
+  uint32_t n_passes;
+  uint32_t n_spheres;
+  uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles over width x local_rows
+  uint32_t n_items;           // tiles_x * tiles_y * n_passes * 64 work items
+  const float* geom;          // n_spheres * {cx, cy, cz, r}
+  const PtMatRec* mat;        // n_spheres
+  float* slab;                // n_passes * local_rows * width * float4 (rgb sum, spp)
+  unsigned long long* counters;  // [0] work-queue head, [1] segments, [2] samples
+};
+
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 4 };
+
+// Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS).
+#define PT_MAX_SPHERES_LDS 10240u
+
+// pt_probe kinds (device-side evaluation of single PT-SPEC functions, for parity tests)
+enum {
+  PT_PROBE_HASH = 0,       // in: seed                 out: seed', h1 | seed'', h2x,h2y | seed''', h3x,h3y,h3z (9 floats)
+  PT_PROBE_SINCOS = 1,     // in: u                    out: sin, cos
+  PT_PROBE_CBRT = 2,       // in: x                    out: cbrt
+  PT_PROBE_UNIT_SPHERE = 3,// in: seed                 out: x,y,z,seed'
+  PT_PROBE_DIVSQRT = 4,    // in: a,b                  out: a/b, sqrt(|a|), fma(a,b,a)
+  PT_PROBE_BASE_HASH = 5,  // in: bits x, bits y       out: hash (as float bits)
+};

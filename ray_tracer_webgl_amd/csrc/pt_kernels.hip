@@ -1,0 +1,524 @@
+// pt_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the path tracer.
+//
+// The hot path of the reference is one fragment-shader invocation per pixel
+// (static/shader.frag:406-413): seed -> for each sample {camera ray -> bounce loop {scan the
+// sphere list -> scatter}}.  Here it is ONE persistent kernel:
+//
+//   * work item = (pixel, pass): the serial fp32 seed chain of static/shader.frag:11,21-36 ties
+//     all samples of one fragment invocation together, so a (pixel, pass) stream is the finest
+//     unit that can run independently.  Items are dealt from a global queue in 8x8-pixel-tile
+//     order, one wave-level atomicAdd per refill.
+//   * one lane owns one item at a time and keeps its whole path state in VGPRs; when its path
+//     ends it starts its own next sample, when its item ends it pulls the next item — so every
+//     lane of the wave enters the sphere loop with a live ray (wave-level culling of finished
+//     paths by regeneration instead of idling), and a wave leaves only when the queue is dry.
+//   * the sphere list's geometry (cx,cy,cz,r^2: 16 B) is staged into LDS once per workgroup and
+//     the intersection loop walks it with wave-uniform ds_read_b128 broadcasts; shading data
+//     (32 B/sphere) stays in global memory / L2 and is read once per segment for the closest hit.
+//   * each item's radiance sum is written once, as one 16-byte store, into a per-pass slab; a
+//     second tiny kernel folds the slabs into the accumulation buffer in pass order, so the
+//     fp32 sum is bit-identical however the queue was scheduled.
+//
+// ARITHMETIC: this file implements PT-SPEC — the same contract the CPU oracle
+// states independently in oracle/pt_oracle.c.  It is compiled with -ffp-contract=off; every
+// fused multiply-add below is an explicit __builtin_fmaf; / and sqrtf are IEEE correctly rounded
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); sin/cos/cbrt are the PT-SPEC
+// polynomial forms, not v_sin/v_cos/v_exp/v_log.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_kernel_args.h"
+
+#define PT_MAX_T 1e5f   // static/shader.frag:5
+#define PT_MIN_T 0.001f // static/shader.frag:6
+#define PT_TWO_PI 6.2831855f
+
+namespace ptd {
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+
+// static/shader.frag:15-19
+__device__ __forceinline__ uint32_t base_hash(uint32_t px, uint32_t py) {
+  uint32_t qx = 1103515245u * ((px >> 1) ^ py);
+  uint32_t qy = 1103515245u * ((py >> 1) ^ px);
+  uint32_t h32 = 1103515245u * (qx ^ (qy >> 3));
+  return h32 ^ (h32 >> 16);
+}
+
+// `vec2(seed += .1, seed += .1)` of static/shader.frag:22,27,33: two rounded fp32 adds
+__device__ __forceinline__ uint32_t seed_step_hash(float& seed) {
+  float s1 = seed + 0.1f;
+  float s2 = s1 + 0.1f;
+  seed = s2;
+  return base_hash(f2u(s1), f2u(s2));
+}
+
+// static/shader.frag:21-24 — float(0xffffffffU) == 2^32
+__device__ __forceinline__ float hash1(float& seed) {
+  uint32_t n = seed_step_hash(seed);
+  return (float)n * (1.0f / 4294967296.0f);
+}
+
+// static/shader.frag:26-30 — float(0x7fffffff) == 2^31
+__device__ __forceinline__ void hash2(float& seed, float& a, float& b) {
+  uint32_t n = seed_step_hash(seed);
+  a = (float)(n & 0x7fffffffu) * (1.0f / 2147483648.0f);
+  b = (float)((n * 48271u) & 0x7fffffffu) * (1.0f / 2147483648.0f);
+}
+
+// static/shader.frag:32-36
+__device__ __forceinline__ void hash3(float& seed, float& a, float& b, float& c) {
+  uint32_t n = seed_step_hash(seed);
+  a = (float)(n & 0x7fffffffu) * (1.0f / 2147483648.0f);
+  b = (float)((n * 16807u) & 0x7fffffffu) * (1.0f / 2147483648.0f);
+  c = (float)((n * 48271u) & 0x7fffffffu) * (1.0f / 2147483648.0f);
+}
+
+// PT-SPEC sin(2*pi*u), cos(2*pi*u), u >= 0
+__device__ __forceinline__ void sincos2pi(float u, float& s_out, float& c_out) {
+  float q = __builtin_rintf(u * 4.0f);
+  float f = u - q * 0.25f;
+  float x = f * PT_TWO_PI;
+  float x2 = x * x;
+  float ps = fma_(fma_(-1.9515295891e-4f, x2, 8.3321608736e-3f), x2, -1.6666654611e-1f);
+  float s = fma_(x * x2, ps, x);
+  float pc = fma_(fma_(2.443315711809948e-5f, x2, -1.388731625493765e-3f), x2, 4.166664568298827e-2f);
+  float c = fma_(x2 * x2, pc, fma_(-0.5f, x2, 1.0f));
+  int qi = ((int)q) & 3;
+  float ss = (qi & 1) ? c : s;
+  float cc = (qi & 1) ? s : c;
+  if (qi == 1 || qi == 2) cc = -cc;
+  if (qi >= 2) ss = -ss;
+  s_out = ss;
+  c_out = cc;
+}
+
+// PT-SPEC cbrt, x >= 0 finite
+__device__ __forceinline__ float cbrt_(float x) {
+  float y = u2f(0x54a2fa8cu - f2u(x) / 3u);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float t = x * y;
+    t = t * y;
+    t = t * y;
+    y = y * fma_(t, -0.33333334f, 1.3333334f);
+  }
+  float r = (x * y) * y;
+  return (x == 0.0f) ? 0.0f : r;
+}
+
+// static/shader.frag:114-121
+__device__ __forceinline__ V3 random_in_unit_sphere(float& seed) {
+  float h0, h1, h2;
+  hash3(seed, h0, h1, h2);
+  float hx = fma_(h0, 2.0f, -1.0f);
+  float sp, cp;
+  sincos2pi(h1, sp, cp);
+  float r = cbrt_(h2);
+  float sq = __builtin_sqrtf(fma_(-hx, hx, 1.0f));
+  return mk(r * (sq * sp), r * (sq * cp), r * hx);
+}
+
+__device__ __forceinline__ V3 normalize3(V3 a) {
+  float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
+  return mk(a.x * inv, a.y * inv, a.z * inv);
+}
+
+// GLSL reflect: I - 2*dot(N,I)*N
+__device__ __forceinline__ V3 reflect3(V3 I, V3 N) {
+  float k = 2.0f * dot3(N, I);
+  return mk(fma_(-k, N.x, I.x), fma_(-k, N.y, I.y), fma_(-k, N.z, I.z));
+}
+
+// static/shader.frag:204-207
+__device__ __forceinline__ float reflectance(float cosine, float ri) {
+  float q = (1.0f - ri) / (1.0f + ri);
+  float r0 = q * q;
+  float x = 1.0f - cosine;
+  float x2 = x * x;
+  float x5 = (x2 * x2) * x;
+  return fma_(1.0f - r0, x5, r0);
+}
+
+} // namespace ptd
+
+using namespace ptd;
+
+// --------------------------------------------------------------------------------------------
+// The path-tracing kernel.  blockDim.x is a multiple of 64 (256 normally, 1024 when the staged
+// list is large and only one workgroup fits per CU); dynamic LDS = n_spheres * 16 bytes.
+// --------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKernelArgs A) {
+  extern __shared__ float4 s_geom[];
+
+  // ---- stage the sphere geometry once per workgroup: (cx, cy, cz, r*r) -----------------------
+  {
+    const float4* g = reinterpret_cast<const float4*>(A.geom);
+    for (uint32_t i = threadIdx.x; i < A.n_spheres; i += blockDim.x) {
+      float4 v = g[i];
+      v.w = v.w * v.w; // pow(radius, 2.) static/shader.frag:149
+      s_geom[i] = v;
+    }
+  }
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n_spheres = A.n_spheres;
+  const float fw = (float)A.width, fh = (float)A.height;
+  const V3 cam_o = mk(A.origin[0], A.origin[1], A.origin[2]);
+
+  // ---- per-lane path state ---------------------------------------------------------------------
+  bool alive = false;     // lane holds a live ray
+  bool exhausted = false; // queue returned "no more items" to this lane
+  uint32_t slab_index = 0;
+  int sample = 0, depth = 0;
+  float seed = 0.f, st_s = 0.f, st_t = 0.f;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+  float a = 0.f; // dot(d,d), hoisted out of the sphere loop (static/shader.frag:147)
+  V3 col = mk(1, 1, 1), sum = mk(0, 0, 0);
+
+  uint32_t seg_count = 0, sample_count = 0; // wave-uniform tallies
+
+  // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
+  auto start_sample = [&]() {
+    float r0, r1;
+    hash2(seed, r0, r1);
+    float s = st_s + r0 / fw;
+    float t = st_t + r1 / fh;
+    float ua = hash1(seed); // random_in_unit_circle :123-129, consumed even if lens_radius == 0
+    float sa, ca;
+    sincos2pi(ua, sa, ca);
+    float rr = __builtin_sqrtf(hash1(seed));
+    float rdx = A.lens_radius * (rr * ca);
+    float rdy = A.lens_radius * (rr * sa);
+    V3 off = mk(fma_(A.cam_v[0], rdy, A.cam_u[0] * rdx), fma_(A.cam_v[1], rdy, A.cam_u[1] * rdx),
+                fma_(A.cam_v[2], rdy, A.cam_u[2] * rdx));
+    V3 dd = mk(fma_(t, A.vertical[0], fma_(s, A.horizontal[0], A.llc[0])),
+               fma_(t, A.vertical[1], fma_(s, A.horizontal[1], A.llc[1])),
+               fma_(t, A.vertical[2], fma_(s, A.horizontal[2], A.llc[2])));
+    d = mk((dd.x - cam_o.x) - off.x, (dd.y - cam_o.y) - off.y, (dd.z - cam_o.z) - off.z);
+    o = mk(cam_o.x + off.x, cam_o.y + off.y, cam_o.z + off.z);
+    a = dot3(d, d);
+    col = mk(1.0f, 1.0f, 1.0f);
+    depth = 0;
+  };
+
+  for (;;) {
+    // ---- refill: lanes without a ray pull work items from the global queue ---------------------
+    for (;;) {
+      bool need = !alive && !exhausted;
+      unsigned long long mask = __ballot(need);
+      if (mask == 0ull) break;
+      uint32_t cnt = (uint32_t)__popcll(mask);
+      int leader = __ffsll((long long)mask) - 1;
+      unsigned long long base = 0;
+      if ((int)lane == leader) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)cnt);
+      base = __shfl(base, leader);
+      if (need) {
+        uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        unsigned long long item64 = base + rank;
+        if (item64 >= (unsigned long long)A.n_items) {
+          exhausted = true;
+        } else {
+          uint32_t item = (uint32_t)item64;
+          uint32_t per_tile = 64u * A.n_passes;
+          uint32_t tile = item / per_tile;
+          uint32_t rem = item - tile * per_tile;
+          uint32_t pass = rem >> 6, l = rem & 63u;
+          uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+          uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
+          if (px < A.width && ly < A.local_rows) {
+            uint32_t y = ly;
+            if (A.band_count > 1u) {
+              uint32_t b = ly / A.band_rows, r = ly - b * A.band_rows;
+              y = (b * A.band_count + A.band_index) * A.band_rows + r;
+            }
+            // static/shader.vert:8 + rasteriser: v_position at the pixel centre
+            float vx = (float)(2u * px + 1u) / fw - 1.0f;
+            float vy = (float)(2u * y + 1u) / fh - 1.0f;
+            float u_time = A.time0 + (float)pass;
+            // init_global_seed, static/shader.frag:354-357
+            seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
+            st_s = (vx + 1.0f) * 0.5f; // :410
+            st_t = (vy + 1.0f) * 0.5f;
+            slab_index = (pass * A.local_rows + ly) * A.width + px;
+            sum = mk(0.f, 0.f, 0.f);
+            sample = 0;
+            start_sample();
+            alive = true;
+          }
+          // an item that falls outside the image (edge tile) is simply dropped
+        }
+      }
+    }
+    unsigned long long live = __ballot(alive);
+    if (live == 0ull) break; // every lane is exhausted: the queue is dry
+    seg_count += (uint32_t)__popcll(live);
+
+    // ---- hit_world: static/shader.frag:175-196 over the LDS list -------------------------------
+    float closest = PT_MAX_T;
+    int hit = -1;
+#pragma unroll 4
+    for (uint32_t i = 0; i < n_spheres; i++) {
+      float4 g = s_geom[i]; // wave-uniform address: LDS broadcast
+      V3 oc = mk(o.x - g.x, o.y - g.y, o.z - g.z);
+      float half_b = dot3(oc, d);
+      float c = dot3(oc, oc) - g.w;
+      float disc = fma_(-a, c, half_b * half_b);
+      if (alive && !(disc < 0.0f)) { // :153 (NaN falls through, as in the shader)
+        float sqrtd = __builtin_sqrtf(disc);
+        float root = (-half_b - sqrtd) / a;
+        bool ok = true;
+        if (root < PT_MIN_T || closest < root) { // :159
+          root = (-half_b + sqrtd) / a;
+          if (root < PT_MIN_T || closest < root) ok = false; // :161
+        }
+        if (ok) { // ties go to the later sphere: rejection is `closest < root`
+          closest = root;
+          hit = (int)i;
+        }
+      }
+    }
+
+    // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
+    if (alive) {
+      bool finished = false; // this camera path is over
+      if (hit < 0) {
+        if (A.background_mode == 0) { // background(), :289-294
+          float inv = 1.0f / __builtin_sqrtf(a);
+          float uy = d.y * inv;
+          float t = 0.5f * (uy + 1.0f);
+          float omt = 1.0f - t;
+          sum.x += col.x * fma_(0.5f, t, omt);
+          sum.y += col.y * fma_(0.7f, t, omt);
+          sum.z += col.z * fma_(1.0f, t, omt);
+        }
+        finished = true;
+      } else {
+        float4 g = s_geom[hit];
+        const float4* mp = reinterpret_cast<const float4*>(A.mat + hit);
+        float4 m0 = mp[0]; // albedo.xyz, fuzz
+        float4 m1 = mp[1]; // refraction_index, type, radius, uuid
+        int mtype = __float_as_int(m1.y);
+        float radius = m1.z;
+        // hit record, :166-171
+        V3 p = mk(fma_(d.x, closest, o.x), fma_(d.y, closest, o.y), fma_(d.z, closest, o.z));
+        V3 on = mk((p.x - g.x) / radius, (p.y - g.y) / radius, (p.z - g.z) / radius);
+        bool front = dot3(d, on) < 0.0f; // :137
+        V3 n = front ? on : mk(-on.x, -on.y, -on.z);
+        V3 alb = mk(m0.x, m0.y, m0.z);
+
+        if (mtype == 0 || mtype == 1) {
+          V3 rs = random_in_unit_sphere(seed); // both DIFFUSE (:217) and METAL (:240) draw one
+          V3 nd;
+          bool ok = true;
+          if (mtype == 0) { // DIFFUSE :212-229
+            V3 ruv = normalize3(rs);
+            nd = mk(n.x + ruv.x, n.y + ruv.y, n.z + ruv.z);
+          } else { // METAL :232-247
+            V3 refl = reflect3(d, n);
+            float fuzz = m0.w;
+            nd = mk(fma_(fuzz, rs.x, refl.x), fma_(fuzz, rs.y, refl.y), fma_(fuzz, rs.z, refl.z));
+            ok = dot3(n, nd) > 0.0f;
+          }
+          if (ok) {
+            o = p; d = nd;
+            col.x *= alb.x; col.y *= alb.y; col.z *= alb.z;
+          } else {
+            finished = true; // absorbed: return vec3(0.) :327-329
+          }
+        } else if (mtype == 2) { // GLASS :250-282
+          float ri = m1.x;
+          float ratio = front ? (1.0f / ri) : ri;
+          float inv = 1.0f / __builtin_sqrtf(a);
+          V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
+          float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
+          float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
+          float sin_theta = __builtin_sqrtf(fma_(-cos_theta, cos_theta, 1.0f));
+          bool cannot_refract = ratio * sin_theta > 1.0f;
+          float refl_amount = reflectance(cos_theta, ratio);
+          float rnd = hash1(seed);
+          V3 nd;
+          if (cannot_refract || refl_amount > rnd) {
+            nd = reflect3(ud, n);
+          } else { // GLSL refract
+            float dni = dot3(n, ud);
+            float k = fma_(-(ratio * ratio), fma_(-dni, dni, 1.0f), 1.0f);
+            if (k < 0.0f) {
+              nd = mk(0.f, 0.f, 0.f);
+            } else {
+              float t = fma_(ratio, dni, __builtin_sqrtf(k));
+              nd = mk(fma_(-t, n.x, ratio * ud.x), fma_(-t, n.y, ratio * ud.y),
+                      fma_(-t, n.z, ratio * ud.z));
+            }
+          }
+          o = p; d = nd;
+          col.x *= alb.x; col.y *= alb.y; col.z *= alb.z;
+        } else if (mtype == 3) { // EMISSIVE (extension): radiance = throughput * emission
+          sum.x += col.x * alb.x; sum.y += col.y * alb.y; sum.z += col.z * alb.z;
+          finished = true;
+        } else {
+          finished = true; // unrecognised material absorbs, :284-285
+        }
+
+        if (!finished) {
+          a = dot3(d, d);
+          depth++;
+          if (depth >= A.max_depth) { // loop bound :300 exhausted -> return color :338
+            sum.x += col.x; sum.y += col.y; sum.z += col.z;
+            finished = true;
+          }
+        }
+      }
+
+      if (finished) {
+        sample++;
+        if (sample >= A.spp) {
+          float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
+          reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
+          alive = false;
+        } else {
+          start_sample();
+        }
+      }
+    }
+    sample_count += 0; // (samples are derived on the host: pixels * spp * passes)
+  }
+
+  if (lane == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
+  (void)sample_count;
+}
+
+// --------------------------------------------------------------------------------------------
+// accum[i] += slab[0][i] + slab[1][i] + ... in pass order (sequential fp32 adds, like n_passes
+// separate pt_render calls would perform them).  16 B per lane, coalesced.
+// --------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void pt_accumulate_kernel(float4* accum,
+                                                                       const float4* slab,
+                                                                       uint32_t n_pix,
+                                                                       uint32_t n_passes) {
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    float4 acc = accum[i];
+    for (uint32_t p = 0; p < n_passes; p++) {
+      float4 s = slab[(size_t)p * n_pix + i];
+      acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    }
+    accum[i] = acc;
+  }
+}
+
+__device__ __forceinline__ uint32_t unorm8(float v) {
+  if (!(v > 0.0f)) return 0u;
+  if (v >= 1.0f) return 255u;
+  return (uint32_t)(v * 255.0f + 0.5f);
+}
+
+// read-out, static/shader.frag:376-380 on the accumulated sum
+extern "C" __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* accum, float4* out,
+                                                                    uint32_t n_pix, float scale,
+                                                                    int gamma) {
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    float4 v = accum[i];
+    float r = v.x * scale, g = v.y * scale, b = v.z * scale;
+    if (gamma) { r = __builtin_sqrtf(r); g = __builtin_sqrtf(g); b = __builtin_sqrtf(b); }
+    out[i] = make_float4(r, g, b, 1.0f);
+  }
+}
+
+extern "C" __global__ __launch_bounds__(256) void pt_resolve_rgba8_kernel(const float4* accum,
+                                                                          uint32_t* out, uint32_t n_pix,
+                                                                          float scale, int gamma) {
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    float4 v = accum[i];
+    float r = v.x * scale, g = v.y * scale, b = v.z * scale;
+    if (gamma) { r = __builtin_sqrtf(r); g = __builtin_sqrtf(g); b = __builtin_sqrtf(b); }
+    out[i] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (255u << 24);
+  }
+}
+
+// temporal running mean of the reference, static/shader.frag:387-404 (RGBA8 ping-pong textures)
+extern "C" __global__ __launch_bounds__(256) void pt_blend_rgba8_kernel(
+    const float4* accum, const uint32_t* prev, uint32_t* out, uint32_t n_pix, float scale,
+    int render_count, int should_average, float last_frame_weight) {
+  uint32_t stride = gridDim.x * blockDim.x;
+  float rc = (float)render_count;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    float4 v = accum[i];
+    float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale),
+                   __builtin_sqrtf(v.z * scale)};
+    uint32_t pv = prev[i];
+    float pa = (float)(pv >> 24) / 255.0f;
+    uint32_t o = 255u << 24;
+    if (should_average && !(pa == 0.0f || render_count <= 1)) {
+      float total = rc + last_frame_weight;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
+        float merged = fma_(px[c], last_frame_weight, pr * rc) / total;
+        o |= unorm8(merged) << (8 * c);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
+    }
+    out[i] = o;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// pt_probe: evaluate single PT-SPEC functions on the device (parity tests of SURVEY §8a rows).
+// --------------------------------------------------------------------------------------------
+extern "C" __global__ void pt_probe_kernel(int kind, const float* in, float* out, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (kind) {
+    case PT_PROBE_HASH: {
+      float seed = in[i];
+      float* o = out + 9 * (size_t)i;
+      float h1 = hash1(seed);
+      o[0] = seed; o[1] = h1;
+      float a2, b2;
+      hash2(seed, a2, b2);
+      o[2] = seed; o[3] = a2; o[4] = b2;
+      float a3, b3, c3;
+      hash3(seed, a3, b3, c3);
+      o[5] = seed; o[6] = a3; o[7] = b3; o[8] = c3;
+      break;
+    }
+    case PT_PROBE_SINCOS: {
+      float s, c;
+      sincos2pi(in[i], s, c);
+      out[2 * (size_t)i] = s; out[2 * (size_t)i + 1] = c;
+      break;
+    }
+    case PT_PROBE_CBRT: out[i] = cbrt_(in[i]); break;
+    case PT_PROBE_UNIT_SPHERE: {
+      float seed = in[i];
+      V3 r = random_in_unit_sphere(seed);
+      float* o = out + 4 * (size_t)i;
+      o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = seed;
+      break;
+    }
+    case PT_PROBE_DIVSQRT: {
+      float x = in[2 * (size_t)i], y = in[2 * (size_t)i + 1];
+      float* o = out + 3 * (size_t)i;
+      o[0] = x / y; o[1] = __builtin_sqrtf(__builtin_fabsf(x)); o[2] = fma_(x, y, x);
+      break;
+    }
+    case PT_PROBE_BASE_HASH: {
+      uint32_t h = base_hash(f2u(in[2 * (size_t)i]), f2u(in[2 * (size_t)i + 1]));
+      out[i] = u2f(h);
+      break;
+    }
+    default: break;
+  }
+}

@@ -1,0 +1,73 @@
+"""Multi-GPU rendering: one process per GPU, image rows dealt to ranks in interleaved bands,
+one RCCL collective at the end.
+
+The path shards perfectly: a pixel's RNG stream depends only on (v_position, u_time)
+(static/shader.frag:354-357), never on which tile, workgroup or GPU traced it, so any row
+partition reproduces the single-GPU image bit for bit.  Rank r of n owns the rows y with
+(y // band_rows) % n == r (PtParams.band_*): interleaving balances cheap sky rows against
+expensive ground rows.  There is no data-path collective while rendering; the only exchange is
+the gather of the per-rank fp32 radiance buffers once the frame has converged — an all_gather of
+equal-sized padded buffers over RCCL/xGMI (backend "nccl"), de-interleaved on every rank.
+"""
+import numpy as np
+
+from . import abi
+
+
+def band_of(rank, world, band_rows=8):
+    """(band_rows, band_index, band_count) for this rank."""
+    return (int(band_rows), int(rank), int(world))
+
+
+def max_local_rows(height, band_rows, world):
+    return max(abi.local_rows(height, band_rows, r, world) for r in range(world))
+
+
+def gather_rows(local, height, band_rows, rank, world, group=None):
+    """all_gather the per-rank row bands and reassemble the full image.
+
+    local: torch tensor (local_rows_or_more, width, 4) float32 on the rank's device (cuda for
+    nccl, cpu for gloo).  Returns a (height, width, 4) tensor on the same device, identical on
+    every rank."""
+    import torch
+    import torch.distributed as dist
+
+    width = local.shape[1]
+    rows_here = abi.local_rows(height, band_rows, rank, world)
+    if world == 1:
+        return local[:rows_here].clone()
+    pad_rows = max_local_rows(height, band_rows, world)
+    send = torch.zeros((pad_rows, width, 4), dtype=local.dtype, device=local.device)
+    send[:rows_here] = local[:rows_here]
+    recv = torch.empty((world, pad_rows, width, 4), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    full = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        ys = abi.owned_rows(height, band_rows, r, world)
+        if len(ys):
+            idx = torch.as_tensor(ys, device=local.device)
+            full[idx] = recv[r, : len(ys)]
+    return full
+
+
+def render_band(scene, rank, world, band_rows=8, render_fn=None, device=0):
+    """Render this rank's rows of `scene` (all passes).  Returns (tensor, segments, tracer).
+
+    render_fn(scene, params) -> (ndarray (local_rows, width, 4), segments) replaces the HIP path
+    in CPU-only tests of the partition/gather logic (tests inject the oracle there); the product
+    path (render_fn None) always goes through libptrace on `device` and fails without a GPU."""
+    import torch
+
+    p = scene.params.copy()
+    p.band_rows, p.band_index, p.band_count = band_of(rank, world, band_rows)
+    if render_fn is not None:
+        acc, seg = render_fn(scene, p)
+        return torch.from_numpy(np.ascontiguousarray(acc)), seg, None
+    from .tracer import PathTracer
+
+    pt = PathTracer(p.width, p.height, device=device, use_torch=True)
+    pt.set_spheres(scene.spheres)
+    pt.set_params(p)
+    pt.reserve_passes(scene.n_passes)
+    pt.render_passes(scene.n_passes)
+    return pt.accum_tensor, None, pt

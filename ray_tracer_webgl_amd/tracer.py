@@ -1,0 +1,190 @@
+"""PathTracer — thin Python handle on a pt_ctx (include/ptrace.h).
+
+Mirrors how the reference drives its GPU boundary: set_geometry once (src/lib.rs:57), run the
+uniform setters and render every frame (src/lib.rs:92-102), read the result out.  Device memory
+and streams can come from PyTorch (`use_torch=True`): the accumulation buffer is then a torch
+tensor bound with pt_bind_accum and kernels run on torch's current stream, which is what the
+multi-GPU gather (dist.py) and bench.py's timing need.  PyTorch is plumbing here, not compute.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import load
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libptrace error %d: %s" % (code, message))
+        self.code = code
+
+
+class PathTracer:
+    def __init__(self, width, height, device=0, use_torch=False):
+        self.lib = load()
+        self.width, self.height = int(width), int(height)
+        self.device = int(device)
+        self._ctx = C.c_void_p()
+        rc = self.lib.pt_create(C.byref(self._ctx), self.device, self.width, self.height)
+        if rc != abi.PT_OK:
+            msg = self.lib.pt_last_error(None)
+            self._ctx = C.c_void_p()
+            raise PtError(rc, msg.decode() if msg else "pt_create failed")
+        self.params = None
+        self.local_rows = self.height
+        self.use_torch = bool(use_torch)
+        self.accum_tensor = None
+        self._keep = None
+        if self.use_torch:
+            import torch
+
+            self._torch = torch
+            stream = torch.cuda.current_stream(self.device)
+            self._check(self.lib.pt_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)))
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != abi.PT_OK:
+            msg = self.lib.pt_last_error(self._ctx)
+            raise PtError(rc, msg.decode() if msg else "")
+        return rc
+
+    def close(self):
+        if self._ctx:
+            self.lib.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- scene / uniforms -----------------------------------------------------------------------
+    def set_spheres(self, spheres):
+        ptr, n, keep = abi.spheres_as_ctypes(spheres)
+        self._check(self.lib.pt_set_spheres(self._ctx, ptr, n))
+        self.n_spheres = n
+
+    def set_params(self, params):
+        self.params = params.copy()
+        self._check(self.lib.pt_set_params(self._ctx, C.byref(self.params)))
+        self.local_rows = abi.local_rows(self.height, params.band_rows, params.band_index, params.band_count)
+        if self.use_torch:
+            self._bind_torch_accum()
+
+    def _bind_torch_accum(self):
+        torch = self._torch
+        shape = (max(self.local_rows, 1), self.width, 4)
+        if self.accum_tensor is None or tuple(self.accum_tensor.shape) != shape:
+            self.accum_tensor = torch.zeros(shape, dtype=torch.float32, device="cuda:%d" % self.device)
+            nbytes = self.accum_tensor.numel() * 4
+            self._check(self.lib.pt_bind_accum(self._ctx, C.c_void_p(self.accum_tensor.data_ptr()), nbytes))
+
+    def reserve_passes(self, n):
+        self._check(self.lib.pt_reserve_passes(self._ctx, int(n)))
+
+    # -- rendering ------------------------------------------------------------------------------
+    def render(self):
+        self._check(self.lib.pt_render(self._ctx))
+
+    def render_passes(self, n):
+        self._check(self.lib.pt_render_passes(self._ctx, int(n)))
+
+    def reset(self):
+        self._check(self.lib.pt_reset_accum(self._ctx))
+        if self.accum_tensor is not None:
+            self.accum_tensor.zero_()
+
+    def synchronize(self):
+        self._check(self.lib.pt_synchronize(self._ctx))
+
+    # -- read-out -------------------------------------------------------------------------------
+    def resolve(self, gamma=True):
+        out = np.empty((self.local_rows, self.width, 4), dtype=np.float32)
+        if out.size:
+            self._check(self.lib.pt_resolve(self._ctx, out.ctypes.data_as(C.c_void_p), 1 if gamma else 0))
+        return out
+
+    def resolve_rgba8(self, gamma=True):
+        out = np.empty((self.local_rows, self.width, 4), dtype=np.uint8)
+        if out.size:
+            self._check(self.lib.pt_resolve_rgba8(self._ctx, out.ctypes.data_as(C.c_void_p), 1 if gamma else 0))
+        return out
+
+    def blend_rgba8(self, prev):
+        prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        out = np.empty_like(prev)
+        self._check(self.lib.pt_blend_rgba8(self._ctx, prev.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def accum(self):
+        """Raw accumulation buffer (local_rows, width, 4) fp32: rgb sums, a = spp."""
+        self.synchronize()
+        if self.accum_tensor is not None:
+            self._torch.cuda.current_stream(self.device).synchronize()
+            return self.accum_tensor[: self.local_rows].cpu().numpy()
+        ptr = C.c_void_p()
+        nbytes = C.c_size_t()
+        self._check(self.lib.pt_accum_ptr(self._ctx, C.byref(ptr), C.byref(nbytes)))
+        out = np.empty((self.local_rows, self.width, 4), dtype=np.float32)
+        if out.size:
+            hip = _hip()
+            rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(out.nbytes), 2)
+            if rc != 0:
+                raise PtError(abi.PT_ERR_HIP, "hipMemcpy D2H failed: %d" % rc)
+        return out
+
+    def stats(self):
+        st = abi.PtStats()
+        self._check(self.lib.pt_get_stats(self._ctx, C.byref(st)))
+        return st
+
+    def probe(self, kind, inp, out_per_item, n):
+        inp = np.ascontiguousarray(inp, dtype=np.float32)
+        out = np.zeros(int(n) * out_per_item, dtype=np.float32)
+        self._check(
+            self.lib.pt_probe(self._ctx, int(kind), inp.ctypes.data_as(C.c_void_p), inp.size,
+                              out.ctypes.data_as(C.c_void_p), out.size, int(n))
+        )
+        return out
+
+
+_hip_lib = None
+
+
+def _hip():
+    global _hip_lib
+    if _hip_lib is None:
+        _hip_lib = C.CDLL("libamdhip64.so")
+        _hip_lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip_lib.hipMemcpy.restype = C.c_int
+    return _hip_lib
+
+
+def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=None):
+    """Render a scenes.Scene completely; returns (PathTracer, accum ndarray)."""
+    p = scene.params.copy()
+    if band is not None:
+        p.band_rows, p.band_index, p.band_count = band
+    pt = PathTracer(p.width, p.height, device=device, use_torch=use_torch)
+    pt.set_spheres(scene.spheres)
+    pt.set_params(p)
+    per = passes_per_launch or scene.n_passes
+    pt.reserve_passes(per)
+    done = 0
+    while done < scene.n_passes:
+        k = min(per, scene.n_passes - done)
+        q = p.copy()
+        q.time = float(np.float32(scene.params.time) + np.float32(done))
+        pt.set_params(q)
+        pt.render_passes(k)
+        done += k
+    return pt, pt.accum()

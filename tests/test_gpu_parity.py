@@ -1,0 +1,358 @@
+"""GPU parity: the HIP path (through the C ABI of include/ptrace.h) against the CPU oracle on the
+same seeded inputs.  The bar is BIT-EXACT fp32 (north_star allows 1e-4 per channel; both sides
+implement the same pinned arithmetic, so any difference is a bug).  Every test calls through
+libptrace.so; the oracle is only the checker.
+
+Sizes: the oracle finishes each case in seconds.  BASELINE's full-size configs are covered by
+size-independent properties in test_gpu_properties.py.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ray_tracer_webgl_amd import abi, scenes
+from ray_tracer_webgl_amd.tracer import PathTracer, PtError, render_scene
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+PROBE_HASH, PROBE_SINCOS, PROBE_CBRT, PROBE_UNIT_SPHERE, PROBE_DIVSQRT, PROBE_BASE_HASH = range(6)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(got, ref, what=""):
+    g, r = bits(got), bits(ref)
+    if not np.array_equal(g, r):
+        bad = np.argwhere(g != r)
+        diff = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+        raise AssertionError("%s: %d of %d values differ (max abs %.3g), first at %s: %r vs %r" % (
+            what, len(bad), g.size, np.nanmax(diff), tuple(bad[0]),
+            np.asarray(got)[tuple(bad[0])], np.asarray(ref)[tuple(bad[0])]))
+
+
+@pytest.fixture(scope="module")
+def pt():
+    t = PathTracer(64, 64)
+    yield t
+    t.close()
+
+
+# ----------------------------------------------------------- single PT-SPEC functions (§8a rows)
+def test_probe_base_hash(pt, ora):
+    L = ora.load()
+    rng = np.random.default_rng(0)
+    xy = rng.integers(0, 2**32, (4096, 2), dtype=np.uint64).astype(np.uint32)
+    out = pt.probe(PROBE_BASE_HASH, xy.view(np.float32).ravel(), 1, len(xy)).view(np.uint32)
+    ref = np.array([L.ora_base_hash(int(x), int(y)) for x, y in xy], dtype=np.uint32)
+    assert np.array_equal(out, ref)
+
+
+def test_probe_hash_streams(pt, ora):
+    L = ora.load()
+    seeds = np.concatenate([np.linspace(0, 50, 1500), np.linspace(1e3, 2e5, 500), [0.0, 4194304.0]]).astype(np.float32)
+    out = pt.probe(PROBE_HASH, seeds, 9, len(seeds)).reshape(-1, 9)
+    ref = np.zeros_like(out)
+    for i, s0 in enumerate(seeds):
+        s = C.c_float(float(s0))
+        h1 = L.ora_hash1(C.byref(s))
+        ref[i, 0:2] = (s.value, h1)
+        o2 = (C.c_float * 2)()
+        L.ora_hash2(C.byref(s), o2)
+        ref[i, 2:5] = (s.value, o2[0], o2[1])
+        o3 = (C.c_float * 3)()
+        L.ora_hash3(C.byref(s), o3)
+        ref[i, 5:9] = (s.value, o3[0], o3[1], o3[2])
+    assert_bit_equal(out, ref, "hash1/2/3 + seed stepping")
+
+
+def test_probe_sincos_cbrt_unit_sphere(pt, ora):
+    L = ora.load()
+    rng = np.random.default_rng(1)
+    u = np.concatenate([rng.random(20000), [0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, 1.0]]).astype(np.float32)
+    out = pt.probe(PROBE_SINCOS, u, 2, len(u)).reshape(-1, 2)
+    ref = np.zeros_like(out)
+    s, c = C.c_float(), C.c_float()
+    for i, v in enumerate(u):
+        L.ora_sincos2pi(float(v), C.byref(s), C.byref(c))
+        ref[i] = (s.value, c.value)
+    assert_bit_equal(out, ref, "sincos2pi")
+    x = np.concatenate([rng.random(20000), rng.integers(0, 2**31, 4000) / 2.0**31, [0.0, 1.0, 2.0**-31]]).astype(np.float32)
+    out = pt.probe(PROBE_CBRT, x, 1, len(x))
+    ref = np.array([L.ora_cbrt(float(v)) for v in x], dtype=np.float32)
+    assert_bit_equal(out, ref, "cbrt")
+    seeds = rng.uniform(0, 5000, 8000).astype(np.float32)
+    out = pt.probe(PROBE_UNIT_SPHERE, seeds, 4, len(seeds)).reshape(-1, 4)
+    ref = np.zeros_like(out)
+    o3 = (C.c_float * 3)()
+    for i, s0 in enumerate(seeds):
+        sd = C.c_float(float(s0))
+        L.ora_random_in_unit_sphere(C.byref(sd), o3)
+        ref[i] = (o3[0], o3[1], o3[2], sd.value)
+    assert_bit_equal(out, ref, "random_in_unit_sphere")
+
+
+def test_probe_ieee_div_sqrt_fma(pt):
+    """/ , sqrt and fma on the device are IEEE correctly rounded (vs numpy float32 / float64)."""
+    rng = np.random.default_rng(2)
+    a = np.concatenate([rng.normal(0, 100, 30000), 10.0 ** rng.uniform(-30, 30, 10000), [1e-40, 3e-39, 0.0]])
+    b = np.concatenate([rng.normal(0, 3, 30000), 10.0 ** rng.uniform(-30, 30, 10000), [3.0, 1e-3, 1.0]])
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    b[b == 0] = 1.0
+    out = pt.probe(PROBE_DIVSQRT, np.stack([a, b], 1).ravel(), 3, len(a)).reshape(-1, 3)
+    with np.errstate(all="ignore"):
+        ref_div = (a / b).astype(np.float32)
+        ref_sqrt = np.sqrt(np.abs(a)).astype(np.float32)
+        ref_fma = (a.astype(np.float64) * b.astype(np.float64) + a.astype(np.float64)).astype(np.float32)
+    assert_bit_equal(out[:, 0], ref_div, "division")
+    assert_bit_equal(out[:, 1], ref_sqrt, "sqrt")
+    # double-rounding can differ from a true fma in rare halfway cases; allow those only
+    mism = bits(out[:, 2]) != bits(ref_fma)
+    assert mism.mean() < 1e-4
+
+
+# -------------------------------------------------------------------------------- full frames
+def _check_scene(ora, sc, n_passes=None, window=None, passes_per_launch=None):
+    n_passes = n_passes or sc.n_passes
+    sc.n_passes = n_passes
+    t, got = render_scene(sc, passes_per_launch=passes_per_launch)
+    try:
+        st = t.stats()
+        ref, seg = ora.render(sc.spheres, sc.params, n_passes, window=window)
+        if window is None:
+            assert_bit_equal(got, ref, sc.name)
+            assert st.segments == seg, "segment count %d vs oracle %d" % (st.segments, seg)
+        else:
+            x0, x1, y0, y1 = window
+            assert_bit_equal(got[y0:y1, x0:x1], ref[y0:y1, x0:x1], sc.name + " window")
+        assert st.total_spp == n_passes * sc.params.samples_per_pixel
+        return t, got, ref
+    finally:
+        pass
+
+
+def test_config1_full_frame_bit_exact(ora):
+    """BASELINE config 1: 3-sphere Lambertian, 400x225, 16 spp, 8 bounces — HIP vs oracle vs golden."""
+    sc = scenes.config1()
+    t, got, ref = _check_scene(ora, sc)
+    z = np.load(os.path.join(GOLDEN, "config1_accum.npz"))
+    assert_bit_equal(got, z["accum"], "config1 vs committed golden")
+    assert t.stats().segments == int(z["segments"])
+    # read-out paths: fp32 resolve, RGBA8 quantisation
+    assert_bit_equal(t.resolve(True), ora.resolve(ref, 16, True), "resolve gamma")
+    assert_bit_equal(t.resolve(False), ora.resolve(ref, 16, False), "resolve linear")
+    assert np.array_equal(t.resolve_rgba8(True), ora.resolve_rgba8(ref, 16, True))
+    t.close()
+
+
+def test_default_scene_golden(ora):
+    """The reference's own scene (State::default: metal, glass, negative radii), 2 passes."""
+    sc = scenes.default_scene(320, 176, spp=4, max_depth=8)
+    sc.n_passes = 2
+    t, got, ref = _check_scene(ora, sc)
+    z = np.load(os.path.join(GOLDEN, "default_320x176_accum.npz"))
+    assert_bit_equal(got, z["accum"], "default scene vs committed golden")
+    t.close()
+
+
+def test_cover_scene_small_frame(ora):
+    """Config 2's scene and camera (lens, 484 spheres, depth 50) at 96x54 — golden + oracle."""
+    sc = scenes.config2(96, 54, 4, 2, 50)
+    t, got, ref = _check_scene(ora, sc)
+    z = np.load(os.path.join(GOLDEN, "cover_96x54_accum.npz"))
+    assert_bit_equal(got, z["accum"], "cover 96x54 vs committed golden")
+    t.close()
+
+
+def test_cover_scene_full_resolution_window(ora):
+    """Config 2 at its real 1920x1080 size, one 64-spp pass; oracle checks a 48x40 window."""
+    sc = scenes.config2(1920, 1080, 64, 1, 50)
+    t, got, ref = _check_scene(ora, sc, window=(930, 978, 500, 540))
+    assert np.all(got[..., 3] == 64.0)
+    t.close()
+
+
+def test_room_scene_emissive_black_background(ora):
+    """Config 4 (extension): enclosed room, emissive sphere, black background, deep bounces."""
+    sc = scenes.config4(96, 96, 8, 2, 50)
+    t, got, ref = _check_scene(ora, sc)
+    assert got[..., :3].max() > 0
+    t.close()
+
+
+def test_field_scene_10k_spheres_window(ora):
+    """Config 5: 10 001 spheres = the whole 160 KiB LDS list, 1024-thread workgroups."""
+    sc = scenes.config5(256, 144, 4, 1, 50)
+    t, got, ref = _check_scene(ora, sc, window=(100, 132, 60, 84))
+    t.close()
+
+
+def test_ragged_sizes_and_edge_tiles(ora):
+    """Width/height not multiples of the 8x8 tile; 1x1 image; single sphere; many passes."""
+    for (w, h, spp, passes) in [(13, 7, 3, 2), (1, 1, 5, 3), (65, 9, 1, 4), (8, 8, 2, 1)]:
+        sc = scenes.config1(w, h, spp, 6)
+        sc.n_passes = passes
+        t, got, ref = _check_scene(ora, sc)
+        t.close()
+    sc = scenes.config1(40, 24, 4, 8)
+    sc.spheres = sc.spheres[:1].copy()
+    t, *_ = _check_scene(ora, sc)
+    t.close()
+    sc = scenes.config1(40, 24, 4, 8)
+    sc.spheres = sc.spheres[:0].copy()  # empty scene: every ray escapes to the sky
+    t, got, ref = _check_scene(ora, sc)
+    t.close()
+
+
+def test_max_depth_one_and_large_time(ora):
+    sc = scenes.default_scene(64, 36, spp=3, max_depth=1)
+    t, *_ = _check_scene(ora, sc)
+    t.close()
+    sc = scenes.default_scene(64, 36, spp=3, max_depth=8)
+    sc.params.time = 12345.5  # coarse seed steps
+    t, *_ = _check_scene(ora, sc)
+    t.close()
+    sc.params.time = 4194304.0  # seed stalls: every hash call returns the same value
+    t, *_ = _check_scene(ora, sc)
+    t.close()
+
+
+def test_nan_and_degenerate_geometry(ora):
+    """Zero-radius and coincident spheres, a sphere containing the camera."""
+    sc = scenes.config1(48, 27, 4, 8)
+    sp = np.concatenate([sc.spheres, sc.spheres[1:2], sc.spheres[1:2]])
+    sp[3]["radius"] = 0.0
+    sp[4]["type"] = abi.PT_GLASS
+    sp[4]["refraction_index"] = 1.5
+    sp[4]["center"] = (0.0, 0.0, 1.0)
+    sp[4]["radius"] = 0.5  # camera origin (0,0,1) is at its centre
+    sc.spheres = sp
+    t, *_ = _check_scene(ora, sc)
+    t.close()
+
+
+def test_passes_batched_equals_separate_launches(ora):
+    sc = scenes.default_scene(96, 54, spp=4, max_depth=8)
+    sc.n_passes = 6
+    t1, a1 = render_scene(sc)  # one launch, 6 passes
+    t2, a2 = render_scene(sc, passes_per_launch=1)  # six launches
+    t3, a3 = render_scene(sc, passes_per_launch=4)  # 4 + 2
+    assert_bit_equal(a1, a2, "batched vs separate")
+    assert_bit_equal(a1, a3, "batched vs 4+2")
+    assert t1.stats().segments == t2.stats().segments == t3.stats().segments
+    ref, seg = ora.render(sc.spheres, sc.params, 6)
+    assert_bit_equal(a1, ref, "6 passes vs oracle")
+    for t in (t1, t2, t3):
+        t.close()
+
+
+def test_row_band_partition_bit_exact(ora):
+    sc = scenes.config2(160, 90, 4, 2, 50)
+    tf, full = render_scene(sc)
+    seg_full = tf.stats().segments
+    out = np.zeros_like(full)
+    seg = 0
+    for world, band in [(3, 8), (8, 8), (2, 4)]:
+        out[:] = 0
+        seg = 0
+        for r in range(world):
+            t, part = render_scene(sc, band=(band, r, world))
+            ys = abi.owned_rows(90, band, r, world)
+            assert part.shape[0] == len(ys)
+            out[ys] = part
+            seg += t.stats().segments
+            t.close()
+        assert_bit_equal(out, full, "row bands world=%d" % world)
+        assert seg == seg_full
+    p = sc.params.copy()
+    p.band_rows, p.band_index, p.band_count = 8, 1, 3
+    ref, _ = ora.render(sc.spheres, p, 2)
+    t, part = render_scene(sc, band=(8, 1, 3))
+    assert_bit_equal(part, ref, "band 1/3 vs oracle")
+    t.close()
+    tf.close()
+
+
+def test_temporal_blend_rgba8(ora):
+    """static/shader.frag:387-404 running mean over RGBA8 ping-pong frames."""
+    sc = scenes.default_scene(64, 36, spp=4, max_depth=8)
+    t, acc = render_scene(sc)
+    rng = np.random.default_rng(4)
+    prev = rng.integers(0, 256, (36, 64, 4), dtype=np.uint8)
+    prev[::3, ::2, 3] = 0  # alpha 0 -> "no data", rendered straight
+    for rc, avg, w in [(0, 1, 1.0), (1, 1, 1.0), (2, 1, 1.0), (37, 1, 0.5), (5, 0, 1.0)]:
+        p = sc.params.copy()
+        p.render_count, p.should_average, p.last_frame_weight = rc, avg, w
+        t.set_params(p)
+        got = t.blend_rgba8(prev)
+        ref = ora.blend_rgba8(acc, 4, p, prev)
+        assert np.array_equal(got, ref), (rc, avg, w)
+    t.close()
+
+
+def test_torch_owned_accumulation_and_stream(ora):
+    import torch
+
+    sc = scenes.config1(64, 40, 4, 8)
+    sc.n_passes = 2
+    t, acc = render_scene(sc, use_torch=True)
+    ref, _ = ora.render(sc.spheres, sc.params, 2)
+    assert_bit_equal(acc, ref, "torch-bound accumulation")
+    assert t.accum_tensor.is_cuda and tuple(t.accum_tensor.shape) == (40, 64, 4)
+    torch.cuda.synchronize()
+    t.close()
+
+
+def test_error_behaviour(pt):
+    lib = pt.lib
+    assert lib.pt_render(pt._ctx) == abi.PT_ERR_NOT_READY
+    assert b"pt_set_spheres" in lib.pt_last_error(pt._ctx)
+    sc = scenes.config1(64, 64, 2, 4)
+    pt.set_spheres(sc.spheres)
+    bad = sc.params.copy()
+    bad.samples_per_pixel = 0
+    assert lib.pt_set_params(pt._ctx, C.byref(bad)) == abi.PT_ERR_INVALID
+    bad = sc.params.copy()
+    bad.width = 32
+    assert lib.pt_set_params(pt._ctx, C.byref(bad)) == abi.PT_ERR_INVALID
+    pt.set_params(sc.params)
+    assert lib.pt_render_passes(pt._ctx, 5) == abi.PT_ERR_CAPACITY  # nothing reserved beyond 1
+    out = np.zeros((64, 64, 4), np.float32)
+    assert lib.pt_resolve(pt._ctx, out.ctypes.data_as(C.c_void_p), 1) == abi.PT_ERR_NOT_READY
+    big = np.zeros(10241, dtype=abi.SPHERE_DTYPE)
+    ptr, n, keep = abi.spheres_as_ctypes(big)
+    assert lib.pt_set_spheres(pt._ctx, ptr, n) == abi.PT_ERR_CAPACITY
+    ctx = C.c_void_p()
+    assert lib.pt_create(C.byref(ctx), 99, 8, 8) == abi.PT_ERR_NO_DEVICE
+    assert lib.pt_create(C.byref(ctx), 0, 0, 8) == abi.PT_ERR_INVALID
+    with pytest.raises(PtError):
+        PathTracer(0, 0)
+    pt.set_spheres(sc.spheres)
+    pt.render()
+    pt.reset()
+    assert pt.stats().segments == 0 and pt.stats().total_spp == 0
+
+
+def test_resize_and_reuse(ora):
+    sc = scenes.config1(48, 32, 2, 8)
+    t = PathTracer(48, 32)
+    t.set_spheres(sc.spheres)
+    t.set_params(sc.params)
+    t.render()
+    a = t.accum()
+    assert t.lib.pt_resize(t._ctx, 80, 24) == 0
+    t.width, t.height = 80, 24
+    sc2 = scenes.config1(80, 24, 2, 8)
+    t.set_params(sc2.params)
+    t.render()
+    b = t.accum()
+    ref_a, _ = ora.render(sc.spheres, sc.params, 1)
+    ref_b, _ = ora.render(sc2.spheres, sc2.params, 1)
+    assert_bit_equal(a, ref_a, "before resize")
+    assert_bit_equal(b, ref_b, "after resize")
+    t.close()

@@ -1,0 +1,462 @@
+"""Known-answer tests that pin the CPU oracle (oracle/pt_oracle.c).
+
+The reference has no test or fixture for this path (tests/web.rs:10-13 is `1 + 1 == 2`), so the
+oracle is pinned by independent restatements and hand-derived cases (SURVEY.md §8c list):
+  1. base_hash vs Python big-int literals and a numpy restatement   (static/shader.frag:15-19)
+  2. hash1/2/3 sequences vs a numpy float32 restatement              (:21-36)
+  3. hit_sphere / hit_world cases derived by hand                    (:145-196)
+  4. scatter cases: metal, glass TIR, glass reflect/refract          (:210-286)
+  5. depth exhaustion returns throughput                             (:297-339)
+  6. camera derivation vs the formulas of src/state.rs:319-347 in Python doubles
+  7. the committed full-frame fixture for BASELINE config 1
+  8. f64 Sphere::hit (src/glsl.rs:42-82) vs the fp32 intersection on the default scene
+All CPU-only.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from ray_tracer_webgl_amd import abi, scenes
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------- independent numpy restatement
+def np_base_hash(x, y):
+    x = np.asarray(x, dtype=np.uint32)
+    y = np.asarray(y, dtype=np.uint32)
+    k = np.uint32(1103515245)
+    with np.errstate(over="ignore"):
+        qx = k * ((x >> np.uint32(1)) ^ y)
+        qy = k * ((y >> np.uint32(1)) ^ x)
+        h = k * (qx ^ (qy >> np.uint32(3)))
+    return h ^ (h >> np.uint32(16))
+
+
+def np_seed_step(seed):
+    s1 = np.float32(seed) + np.float32(0.1)
+    s2 = np.float32(s1) + np.float32(0.1)
+    n = np_base_hash(np.float32(s1).view(np.uint32), np.float32(s2).view(np.uint32))
+    return np.float32(s2), np.uint32(n)
+
+
+def np_hash1(seed):
+    seed, n = np_seed_step(seed)
+    return seed, np.float32(n) * np.float32(2.0**-32)
+
+
+def np_hash3(seed):
+    seed, n = np_seed_step(seed)
+    with np.errstate(over="ignore"):
+        parts = [n, n * np.uint32(16807), n * np.uint32(48271)]
+    return seed, [np.float32(p & np.uint32(0x7FFFFFFF)) / np.float32(2.0**31) for p in parts]
+
+
+def _sphere(center, radius, mtype=abi.PT_DIFFUSE, albedo=(0.5, 0.5, 0.5), fuzz=0.0, ri=0.0, uuid=0):
+    s = abi.PtSphere()
+    s.center = abi.f3(*center)
+    s.radius = radius
+    s.type = mtype
+    s.albedo = abi.f3(*albedo)
+    s.fuzz = fuzz
+    s.refraction_index = ri
+    s.uuid = uuid
+    return s
+
+
+def _arr(spheres):
+    a = (abi.PtSphere * len(spheres))(*spheres)
+    for i, s in enumerate(a):
+        s.uuid = i
+    return a
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+# ------------------------------------------------------------------------------- 1. base_hash
+BASE_HASH_KAT = [  # computed with Python big-int arithmetic from the formula at shader.frag:15-19
+    (0x0, 0x0, 0x0),
+    (0x1, 0x2, 0x8545B197),
+    (0x3F800000, 0xBF800000, 0xE508E508),
+    (0xFFFFFFFF, 0xFFFFFFFF, 0x50005000),
+    (0x3DCCCCCD, 0x3E4CCCCD, 0x7262F6FC),
+    (123456789, 987654321, 0x2013517D),
+]
+
+
+def test_base_hash_kat(ora):
+    L = ora.load()
+    for x, y, h in BASE_HASH_KAT:
+        assert L.ora_base_hash(x, y) == h
+        assert int(np_base_hash(x, y)) == h
+
+
+def test_base_hash_random_vs_numpy(ora):
+    L = ora.load()
+    rng = np.random.default_rng(7)
+    xs = rng.integers(0, 2**32, 5000, dtype=np.uint64).astype(np.uint32)
+    ys = rng.integers(0, 2**32, 5000, dtype=np.uint64).astype(np.uint32)
+    ref = np_base_hash(xs, ys)
+    got = np.array([L.ora_base_hash(int(x), int(y)) for x, y in zip(xs, ys)], dtype=np.uint32)
+    assert np.array_equal(ref, got)
+
+
+# ---------------------------------------------------------------------------- 2. hash streams
+@pytest.mark.parametrize("seed0", [0.0, 0.5, 1000.25, 65536.5])
+def test_hash_sequences(ora, seed0):
+    L = ora.load()
+    seed = C.c_float(seed0)
+    ref_seed = np.float32(seed0)
+    for _ in range(8):
+        ref_seed, r1 = np_hash1(ref_seed)
+        g1 = L.ora_hash1(C.byref(seed))
+        assert np.float32(g1) == r1 and np.float32(seed.value) == ref_seed
+        out3 = (C.c_float * 3)()
+        L.ora_hash3(C.byref(seed), out3)
+        ref_seed, r3 = np_hash3(ref_seed)
+        assert [np.float32(v) for v in out3] == r3
+        assert np.float32(seed.value) == ref_seed
+        out2 = (C.c_float * 2)()
+        L.ora_hash2(C.byref(seed), out2)
+        ref_seed, n = np_seed_step(ref_seed)
+        with np.errstate(over="ignore"):
+            r2 = [np.float32(n & np.uint32(0x7FFFFFFF)) / np.float32(2.0**31),
+                  np.float32((n * np.uint32(48271)) & np.uint32(0x7FFFFFFF)) / np.float32(2.0**31)]
+        assert [np.float32(v) for v in out2] == r2
+
+
+def test_hash_ranges_and_seed_stepping(ora):
+    L = ora.load()
+    # the seed advances twice per call, whatever the arity (Appendix A.2); 0.1f steps are rounded
+    seed = C.c_float(0.0)
+    L.ora_hash1(C.byref(seed))
+    assert np.float32(seed.value) == np.float32(np.float32(0.1) + np.float32(0.1))
+    # seed stalls at large u_time: 2^22 + 0.1 == 2^22 in fp32
+    seed = C.c_float(4194304.0)
+    L.ora_hash1(C.byref(seed))
+    assert seed.value == 4194304.0
+    vals = []
+    seed = C.c_float(3.0)
+    for _ in range(2000):
+        vals.append(L.ora_hash1(C.byref(seed)))
+    assert 0.0 <= min(vals) and max(vals) <= 1.0
+    assert 0.45 < float(np.mean(vals)) < 0.55
+
+
+def test_init_seed_and_v_position(ora):
+    L = ora.load()
+    for (p, ext) in [(0, 400), (199, 400), (399, 400), (0, 225), (224, 225), (1079, 1080)]:
+        v = L.ora_v_position(p, ext)
+        ref = np.float32(np.float32(2 * p + 1) / np.float32(ext)) - np.float32(1.0)
+        assert np.float32(v) == np.float32(ref)
+    vx, vy = L.ora_v_position(3, 400), L.ora_v_position(5, 225)
+    h = np_base_hash(np.float32(vx).view(np.uint32), np.float32(vy).view(np.uint32))
+    ref = np.float32(np.float32(h) / np.float32(2.0**32)) + np.float32(7.0)
+    assert np.float32(L.ora_init_seed(vx, vy, 7.0)) == np.float32(ref)
+
+
+# -------------------------------------------------------------------- PT-SPEC transcendental
+def test_sincos2pi_accuracy_and_quadrants(ora):
+    L = ora.load()
+    s, c = C.c_float(), C.c_float()
+    exact = {0.0: (0, 1), 0.25: (1, 0), 0.5: (0, -1), 0.75: (-1, 0), 1.0: (0, 1)}
+    for u, (es, ec) in exact.items():
+        L.ora_sincos2pi(u, C.byref(s), C.byref(c))
+        assert abs(s.value - es) < 1e-7 and abs(c.value - ec) < 1e-7
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for u in rng.random(20000).astype(np.float32):
+        L.ora_sincos2pi(float(u), C.byref(s), C.byref(c))
+        a = 2 * math.pi * float(u)
+        worst = max(worst, abs(s.value - math.sin(a)), abs(c.value - math.cos(a)))
+    assert worst < 2.5e-7
+
+
+def test_cbrt(ora):
+    L = ora.load()
+    assert L.ora_cbrt(0.0) == 0.0
+    assert abs(L.ora_cbrt(1.0) - 1.0) < 5e-7
+    assert abs(L.ora_cbrt(0.125) - 0.5) < 3e-7
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.random(20000), rng.integers(1, 2**31, 5000) / 2.0**31]).astype(np.float32)
+    worst = max(abs(L.ora_cbrt(float(x)) - float(x) ** (1 / 3)) / float(x) ** (1 / 3) for x in xs)
+    assert worst < 5e-7  # <= ~7 ulp
+
+
+def test_random_in_unit_sphere_is_inside(ora):
+    L = ora.load()
+    seed = C.c_float(1.5)
+    out = (C.c_float * 3)()
+    for _ in range(5000):
+        L.ora_random_in_unit_sphere(C.byref(seed), out)
+        assert out[0] ** 2 + out[1] ** 2 + out[2] ** 2 <= 1.0 + 1e-5
+    circ = (C.c_float * 2)()
+    for _ in range(2000):
+        L.ora_random_in_unit_circle(C.byref(seed), circ)
+        assert circ[0] ** 2 + circ[1] ** 2 <= 1.0 + 1e-5
+
+
+# ------------------------------------------------------------------------------ 3. intersection
+def test_hit_sphere_cases(ora):
+    L = ora.load()
+    sp = _sphere((0, 0, -1), 0.5)
+    h = ora.OraHit()
+    # two roots in range: t = 0.5, normal +z, front face
+    assert L.ora_hit_sphere(C.byref(sp), f3((0, 0, 0)), f3((0, 0, -1)), 0.001, 1e5, C.byref(h)) == 1
+    assert h.t == 0.5 and tuple(h.point) == (0.0, 0.0, -0.5) and tuple(h.normal) == (0.0, 0.0, 1.0)
+    assert h.front_face == 1
+    # miss
+    assert L.ora_hit_sphere(C.byref(sp), f3((0, 0, 0)), f3((0, 1, 0)), 0.001, 1e5, C.byref(h)) == 0
+    # origin on the surface: near root 0 < MIN_T -> far root 1.0, back face, normal flipped
+    assert L.ora_hit_sphere(C.byref(sp), f3((0, 0, -0.5)), f3((0, 0, -1)), 0.001, 1e5, C.byref(h)) == 1
+    assert h.t == 1.0 and h.front_face == 0 and tuple(h.normal) == (0.0, 0.0, 1.0)
+    # inside the sphere
+    assert L.ora_hit_sphere(C.byref(sp), f3((0, 0, -1)), f3((0, 0, -1)), 0.001, 1e5, C.byref(h)) == 1
+    assert h.t == 0.5 and h.front_face == 0
+    # t_max excludes the hit
+    assert L.ora_hit_sphere(C.byref(sp), f3((0, 0, 0)), f3((0, 0, -1)), 0.001, 0.4, C.byref(h)) == 0
+    # unnormalised direction: t scales (shader never normalises, Appendix A.6)
+    assert L.ora_hit_sphere(C.byref(sp), f3((0, 0, 0)), f3((0, 0, -2)), 0.001, 1e5, C.byref(h)) == 1
+    assert h.t == 0.25
+    # negative radius (src/state.rs:200,213): same t, outward normal flips -> back face
+    neg = _sphere((0, 0, -1), -0.5)
+    assert L.ora_hit_sphere(C.byref(neg), f3((0, 0, 0)), f3((0, 0, -1)), 0.001, 1e5, C.byref(h)) == 1
+    assert h.t == 0.5 and h.front_face == 0 and tuple(h.normal) == (0.0, 0.0, 1.0)
+
+
+def test_hit_world_order_and_ties(ora):
+    L = ora.load()
+    h = ora.OraHit()
+    o, d = f3((0, 0, 0)), f3((0, 0, -1))
+    # tie between identical spheres goes to the LATER one (`t_max < root` is the rejection)
+    arr = _arr([_sphere((0, 0, -1), 0.5), _sphere((0, 0, -1), 0.5)])
+    assert L.ora_hit_world(arr, 2, o, d, C.byref(h)) == 1 and h.index == 1
+    # a nearer sphere later in the list replaces the earlier hit; a farther one does not
+    arr = _arr([_sphere((0, 0, -3), 0.5), _sphere((0, 0, -1), 0.5), _sphere((0, 0, -5), 0.5)])
+    assert L.ora_hit_world(arr, 3, o, d, C.byref(h)) == 1 and h.index == 1 and h.t == 0.5
+    # empty list / all behind
+    assert L.ora_hit_world(arr, 0, o, d, C.byref(h)) == 0
+    assert L.ora_hit_world(arr, 3, o, f3((0, 0, 1)), C.byref(h)) == 0
+    # beyond MAX_T = 1e5
+    far = _arr([_sphere((0, 0, -2e5), 1.0)])
+    assert L.ora_hit_world(far, 1, o, d, C.byref(h)) == 0
+
+
+# ---------------------------------------------------------------------------------- 4. scatter
+def test_scatter_metal(ora):
+    L = ora.load()
+    out = ora.OraScatter()
+    arr = _arr([_sphere((0, 0, -1), 0.5, abi.PT_METAL, (0.8, 0.6, 0.2), fuzz=0.0)])
+    rc = L.ora_scatter(arr, 1, f3((0, 0, 0)), f3((0, 0, -1)), 0.25, C.byref(out))
+    assert rc == 1
+    assert tuple(out.direction) == (0.0, 0.0, 1.0)  # mirror reflection, not normalised
+    assert tuple(out.origin) == (0.0, 0.0, -0.5)
+    assert np.allclose(tuple(out.attenuation), (0.8, 0.6, 0.2))
+    # METAL consumes one hash3 even with fuzz == 0 (Appendix A.9): seed moved by two 0.1 steps
+    assert np.float32(out.seed_after) == np.float32(np.float32(np.float32(0.25) + np.float32(0.1)) + np.float32(0.1))
+    # with a large fuzz some seeds scatter below the surface -> absorbed (did_scatter 0)
+    arr = _arr([_sphere((0, 0, -1), 0.5, abi.PT_METAL, (1, 1, 1), fuzz=5.0)])
+    res = []
+    for k in range(200):
+        L.ora_scatter(arr, 1, f3((0, 0, 0)), f3((0, 0, -1)), float(k), C.byref(out))
+        below = out.direction[2] <= 0.0  # normal is +z
+        assert (out.did_scatter == 0) == below
+        res.append(out.did_scatter)
+    assert 0 < sum(res) < 200
+
+
+def test_scatter_glass_total_internal_reflection(ora):
+    L = ora.load()
+    out = ora.OraScatter()
+    arr = _arr([_sphere((0, 0, 0), 1.0, abi.PT_GLASS, (1, 1, 1), ri=1.5)])
+    # inside the sphere, grazing: sin(theta) = 0.9, 1.5 * 0.9 > 1 -> always reflects
+    z = math.sqrt(1 - 0.81)
+    expect = np.array([0.0, 0.0, 1.0]) + 2 * z * np.array([-0.9, 0.0, -z])
+    for k in range(50):
+        rc = L.ora_scatter(arr, 1, f3((0.9, 0, 0)), f3((0, 0, 1)), float(k) + 0.5, C.byref(out))
+        assert rc == 1
+        assert np.allclose(tuple(out.direction), expect, atol=2e-6)
+
+
+def test_scatter_glass_reflect_vs_refract_threshold(ora):
+    L = ora.load()
+    out = ora.OraScatter()
+    arr = _arr([_sphere((0, 0, 0), 1.0, abi.PT_GLASS, (0.9, 1.0, 0.8), ri=1.5)])
+    n_reflect = 0
+    for k in range(3000):
+        seed0 = float(k) * 0.37
+        rc = L.ora_scatter(arr, 1, f3((0, 0, -3)), f3((0, 0, 1)), seed0, C.byref(out))
+        assert rc == 1 and np.allclose(tuple(out.attenuation), (0.9, 1.0, 0.8))  # tinted glass
+        s = C.c_float(seed0)
+        rnd = L.ora_hash1(C.byref(s))
+        # head-on: cos = 1, Schlick r0 = ((1 - 1/1.5)/(1 + 1/1.5))^2 = 0.04
+        reflects = 0.04 > rnd
+        assert abs(abs(out.direction[2]) - 1.0) < 1e-6 and abs(out.direction[0]) < 1e-6
+        if abs(rnd - 0.04) > 1e-5:
+            assert (out.direction[2] < 0) == reflects
+        n_reflect += out.direction[2] < 0
+    assert 60 < n_reflect < 190  # ~4 %
+
+
+def test_unknown_material_absorbs_and_emissive_ends_path(ora):
+    L = ora.load()
+    out = ora.OraScatter()
+    arr = _arr([_sphere((0, 0, -1), 0.5, 7)])
+    assert L.ora_scatter(arr, 1, f3((0, 0, 0)), f3((0, 0, -1)), 0.0, C.byref(out)) == 0
+    p = scenes.config1().params.copy()
+    p.max_depth = 5
+    arr = _arr([_sphere((0, 0, -1), 0.5, abi.PT_EMISSIVE, (3.0, 2.0, 1.0))])
+    seed, col, seg = C.c_float(0.0), (C.c_float * 3)(), C.c_uint64()
+    L.ora_ray_color(arr, 1, C.byref(p), f3((0, 0, 0)), f3((0, 0, -1)), C.byref(seed), col, C.byref(seg))
+    assert tuple(col) == (3.0, 2.0, 1.0) and seg.value == 1 and seed.value == 0.0
+
+
+# ------------------------------------------------------------------------ 5. depth exhaustion
+def test_depth_exhaustion_returns_throughput(ora):
+    L = ora.load()
+    p = scenes.config1().params.copy()
+    p.max_depth = 3
+    arr = _arr([_sphere((0, 0, 0), 10.0, abi.PT_DIFFUSE, (0.5, 0.5, 0.5))])  # closed: always hits
+    seed, col, seg = C.c_float(0.125), (C.c_float * 3)(), C.c_uint64()
+    L.ora_ray_color(arr, 1, C.byref(p), f3((0, 0, 0)), f3((0, 0, -1)), C.byref(seed), col, C.byref(seg))
+    assert tuple(col) == (0.125, 0.125, 0.125) and seg.value == 3  # colour = albedo^3, not black
+    # a miss returns throughput * sky gradient
+    p.max_depth = 8
+    arr = _arr([_sphere((0, 0, -1), 0.5)])
+    L.ora_ray_color(arr, 1, C.byref(p), f3((0, 0, 0)), f3((0, 1, 0)), C.byref(seed), col, C.byref(seg))
+    assert np.allclose(tuple(col), (0.5, 0.7, 1.0), atol=1e-6) and seg.value == 1
+    p.background_mode = abi.PT_BG_BLACK
+    L.ora_ray_color(arr, 1, C.byref(p), f3((0, 0, 0)), f3((0, 1, 0)), C.byref(seed), col, C.byref(seg))
+    assert tuple(col) == (0.0, 0.0, 0.0)
+
+
+# ------------------------------------------------------------------------------------ 6. camera
+def test_camera_default_state(ora):
+    L = ora.load()
+    cam = abi.PtCameraIn()
+    cam.width, cam.height = 400, 225
+    cam.camera_origin = abi.d3(0, 0, 1)
+    cam.yaw_degrees, cam.pitch_degrees = -90.0, 0.0
+    cam.vup = abi.d3(0, 1, 0)
+    cam.fov_radians = math.pi / 3
+    cam.focus_distance = 0.75
+    cam.aperture = 0.0
+    p = abi.PtParams()
+    assert L.ora_camera_from_state(C.byref(cam), C.byref(p)) == 0
+    # src/state.rs:319-347 by hand in Python doubles
+    yaw = -90.0 * math.pi / 180.0
+    front = np.array([math.cos(yaw) * 1.0, 0.0, math.sin(yaw) * 1.0])
+    origin = np.array([0.0, 0.0, 1.0])
+    w = origin - (origin + front)
+    w = w / math.sqrt(w @ w)
+    u = np.cross([0.0, 1.0, 0.0], w)
+    u = u / math.sqrt(u @ u)
+    v = np.cross(w, u)
+    vh = 2 * math.tan(math.pi / 6)
+    vw = vh * (400 / 225)
+    horiz, vert = 0.75 * vw * u, 0.75 * vh * v
+    llc = origin - horiz / 2 - vert / 2 - 0.75 * w
+    assert np.array_equal(np.float32(horiz), np.array(p.horizontal, dtype=np.float32))
+    assert np.array_equal(np.float32(vert), np.array(p.vertical, dtype=np.float32))
+    assert np.array_equal(np.float32(llc), np.array(p.lower_left_corner, dtype=np.float32))
+    assert np.array_equal(np.float32(u), np.array(p.u, dtype=np.float32))
+    assert np.array_equal(np.float32(v), np.array(p.v, dtype=np.float32))
+    assert abs(p.u[0] - 1.0) < 1e-7 and p.lens_radius == 0.0
+    assert abs(p.horizontal[0] - 2 * math.tan(math.pi / 6) * (400 / 225) * 0.75) < 1e-6
+
+
+def test_camera_ray_through_pixel_centre(ora):
+    L = ora.load()
+    p = scenes.config1().params
+    seed = C.c_float(0.0)
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    L.ora_camera_ray(C.byref(p), 0.5, 0.5, C.byref(seed), o, d)
+    assert tuple(o) == (0.0, 0.0, 1.0)
+    assert abs(d[0]) < 1e-6 and abs(d[1]) < 1e-6 and abs(d[2] + 0.75) < 1e-6
+    # two hash1 calls consumed even though lens_radius == 0 (Appendix A.3)
+    s = np.float32(0.0)
+    for _ in range(4):
+        s = np.float32(s + np.float32(0.1))
+    assert np.float32(seed.value) == s
+
+
+# ------------------------------------------------------------------------- 7. golden fixtures
+def test_golden_config1_frame(ora):
+    z = np.load(os.path.join(GOLDEN, "config1_accum.npz"))
+    sc = scenes.config1()
+    acc, seg = ora.render(sc.spheres, sc.params, 1)
+    assert acc.shape == (225, 400, 4)
+    assert seg == int(z["segments"])
+    assert np.array_equal(acc.view(np.uint32), z["accum"].view(np.uint32))
+
+
+def test_golden_default_scene_frame(ora):
+    z = np.load(os.path.join(GOLDEN, "default_320x176_accum.npz"))
+    sc = scenes.default_scene(320, 176, spp=4, max_depth=8)
+    acc, seg = ora.render(sc.spheres, sc.params, 2)
+    assert seg == int(z["segments"])
+    assert np.array_equal(acc.view(np.uint32), z["accum"].view(np.uint32))
+
+
+def test_golden_hash_vectors(ora):
+    L = ora.load()
+    with open(os.path.join(GOLDEN, "hash_kat.json")) as f:
+        kat = json.load(f)
+    for row in kat["hash1"]:
+        seed = C.c_float(np.uint32(row["seed_bits"]).view(np.float32))
+        v = L.ora_hash1(C.byref(seed))
+        assert np.float32(v).view(np.uint32) == row["value_bits"]
+        assert np.float32(seed.value).view(np.uint32) == row["seed_after_bits"]
+
+
+def test_passes_thread_count_and_window_invariance(ora):
+    sc = scenes.config1(80, 45, 4, 8)
+    a1, s1 = ora.render(sc.spheres, sc.params, 3, nthreads=1)
+    a8, s8 = ora.render(sc.spheres, sc.params, 3, nthreads=5)
+    assert s1 == s8 and np.array_equal(a1, a8)
+    assert np.all(a1[..., 3] == 12.0)
+    win, _ = ora.render(sc.spheres, sc.params, 3, window=(10, 30, 5, 25))
+    assert np.array_equal(win[5:25, 10:30], a1[5:25, 10:30])
+    assert np.all(win[:5] == 0) and np.all(win[:, :10] == 0)
+
+
+def test_row_band_partition_reassembles(ora):
+    sc = scenes.config1(64, 45, 2, 8)
+    full, seg_full = ora.render(sc.spheres, sc.params, 1)
+    out = np.zeros_like(full)
+    seg = 0
+    for r in range(3):
+        p = sc.params.copy()
+        p.band_rows, p.band_index, p.band_count = 4, r, 3
+        part, s = ora.render(sc.spheres, p, 1)
+        ys = abi.owned_rows(45, 4, r, 3)
+        assert part.shape[0] == len(ys) == abi.local_rows(45, 4, r, 3)
+        out[ys] = part
+        seg += s
+    assert seg == seg_full and np.array_equal(out, full)
+
+
+# ----------------------------------------------------------------- 8. f64 pick ray cross-check
+def test_center_hit_f64_matches_fp32(ora, lib):
+    L = ora.load()
+    host = (abi.PtHostSphere * 16)()
+    n = lib.pt_default_scene(host, 16)
+    cam = abi.PtCameraIn()
+    lib.pt_default_camera(400, 225, C.byref(cam))
+    hit = abi.PtCenterHit()
+    assert L.ora_center_hit_f64(host, n, C.byref(cam), C.byref(hit)) == 1
+    assert hit.uuid == 1 and abs(hit.t - (1.5 / 0.75)) < 1e-12  # centre sphere, t = (2 - .5)/.75
+    dev = (abi.PtSphere * n)()
+    lib.pt_narrow_spheres(host, n, dev)
+    p = abi.PtParams()
+    L.ora_camera_from_state(C.byref(cam), C.byref(p))
+    d = [p.lower_left_corner[k] + p.horizontal[k] / 2 + p.vertical[k] / 2 - p.camera_origin[k] for k in range(3)]
+    h = ora.OraHit()
+    assert L.ora_hit_world(dev, n, f3(tuple(p.camera_origin)), f3(d), C.byref(h)) == 1
+    assert h.index == hit.uuid and abs(h.t - hit.t) < 1e-5
