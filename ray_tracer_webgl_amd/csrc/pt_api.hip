@@ -530,7 +530,7 @@ PT_API int pt_probe(pt_ctx* c, int kind, const float* in, size_t n_in, float* ou
   PT_HIP(c, hipMalloc(&d_in, n_in * sizeof(float)));
   PT_HIP(c, hipMalloc(&d_out, n_out * sizeof(float)));
   PT_HIP(c, hipMemcpy(d_in, in, n_in * sizeof(float), hipMemcpyHostToDevice));
-  PT_HIP(c, hipMemset(d_out, 0, n_out * sizeof(float)));
+  PT_HIP(c, hipMemsetAsync(d_out, 0, n_out * sizeof(float), c->stream));
   hipLaunchKernelGGL(pt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, kind, d_in, d_out, n);
   PT_HIP(c, hipGetLastError());
   PT_HIP(c, hipStreamSynchronize(c->stream));
