@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's roofline numbers are checked against.
+# Run on the GPU box from the repo root:   bash profiles/collect.sh <tag>
+# Kernel-trace/stats and each PMC group run as SEPARATE rocprofv3 invocations (never combined).
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
+i=0
+for grp in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
+  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32" \
+  "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" \
+  "GRBM_GUI_ACTIVE FETCH_SIZE" \
+  "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1
+done
+python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
