@@ -7,6 +7,7 @@
 // (graph-capturable once pt_reserve_passes has sized the workspace); no CPU fallback exists.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,7 @@ struct pt_ctx {
   float* d_geom = nullptr;
   PtMatRec* d_mat = nullptr;
   uint32_t n_spheres = 0, sphere_cap = 0;
+  bool scene_regular = true;
   bool have_spheres = false, have_params = false;
   PtParams params{};
   uint32_t local_rows = 0;
@@ -183,7 +185,7 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
     return bail(e, "hipMemsetAsync(counters)");
   // allow the trace kernel to use the CU's whole 160 KiB LDS for big sphere lists
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_MAX_SPHERES_LDS * 16);
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -234,7 +236,10 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   // shading record read once per closest hit
   std::vector<float> geom((size_t)n * 4);
   std::vector<PtMatRec> mat(n);
+  bool regular = true;
   for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) regular = regular && (std::fabs(s[i].center[k]) < 1e15f);
+    regular = regular && (std::fabs(s[i].radius) < 1e15f); // NaN fails both
     geom[4 * i + 0] = s[i].center[0];
     geom[4 * i + 1] = s[i].center[1];
     geom[4 * i + 2] = s[i].center[2];
@@ -255,6 +260,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n * sizeof(PtMatRec), hipMemcpyHostToDevice));
   }
   c->n_spheres = n;
+  c->scene_regular = regular;
   c->have_spheres = true;
   return PT_OK;
 }
@@ -395,6 +401,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.band_count = p.band_count;
   A.n_passes = n_passes;
   A.n_spheres = c->n_spheres;
+  A.scene_regular = c->scene_regular ? 1u : 0u;
   A.tiles_x = (c->width + 7) / 8;
   A.tiles_y = (c->local_rows + 7) / 8;
   unsigned long long items = (unsigned long long)A.tiles_x * A.tiles_y * n_passes * 64ull;
@@ -408,7 +415,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
   // per CU when the staged list takes most of the 160 KiB LDS
-  size_t lds = (size_t)c->n_spheres * 16;
+  size_t lds = (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16;
   uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pt_trace_kernel),

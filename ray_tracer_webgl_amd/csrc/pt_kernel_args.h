@@ -28,6 +28,7 @@ struct PtKernelArgs {
   uint32_t band_rows, band_index, band_count;
   uint32_t n_passes;
   uint32_t n_spheres;
+  uint32_t scene_regular;  // every sphere finite with |centre|, |radius| < 1e15 (host-checked)
   uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles over width x local_rows
   uint32_t n_items;           // tiles_x * tiles_y * n_passes * 64 work items
   const float* geom;          // n_spheres * {cx, cy, cz, r}
@@ -38,8 +39,10 @@ struct PtKernelArgs {
 
 enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 4 };
 
-// Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS).
-#define PT_MAX_SPHERES_LDS 10240u
+// Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
+// the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
+#define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
+#define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
 
 // pt_probe kinds (device-side evaluation of single PT-SPEC functions, for parity tests)
 enum {

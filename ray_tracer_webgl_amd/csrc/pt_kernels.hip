@@ -32,6 +32,7 @@
 #define PT_MAX_T 1e5f   // static/shader.frag:5
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
+#define PT_GUARD 1.0000038f // 1 + 2^-18: guard band of the conservative candidate rejections
 
 namespace ptd {
 
@@ -165,6 +166,11 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
       v.w = v.w * v.w; // pow(radius, 2.) static/shader.frag:149
       s_geom[i] = v;
     }
+    // pad to a multiple of 8 plus one prefetch group with a sphere that can never be hit:
+    // beyond MAX_T in every direction, so the literal range test rejects it too
+    const uint32_t n_padded = PT_LDS_ENTRIES(A.n_spheres);
+    for (uint32_t i = A.n_spheres + threadIdx.x; i < n_padded; i += blockDim.x)
+      s_geom[i] = make_float4(1e15f, 1e15f, 1e15f, 0.0f);
   }
   __syncthreads();
 
@@ -262,29 +268,95 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     seg_count += (uint32_t)__popcll(live);
 
     // ---- hit_world: static/shader.frag:175-196 over the LDS list -------------------------------
+    // Four spheres per trip: the next group's four ds_read_b128 are issued before the current
+    // group's arithmetic (LDS latency hides behind ~52 VALU instructions), the four
+    // discriminants are independent (ILP), and one wave-uniform branch guards the rare
+    // candidate work.  Candidates are then taken in list order, so `closest` shrinks exactly
+    // as in the shader's sequential loop.
     float closest = PT_MAX_T;
+    float closest_hi = PT_MAX_T * PT_GUARD; // closest * (1 + 2^-18), see try_candidate
     int hit = -1;
-#pragma unroll 4
-    for (uint32_t i = 0; i < n_spheres; i++) {
-      float4 g = s_geom[i]; // wave-uniform address: LDS broadcast
-      V3 oc = mk(o.x - g.x, o.y - g.y, o.z - g.z);
-      float half_b = dot3(oc, d);
-      float c = dot3(oc, oc) - g.w;
-      float disc = fma_(-a, c, half_b * half_b);
-      if (alive && !(disc < 0.0f)) { // :153 (NaN falls through, as in the shader)
-        float sqrtd = __builtin_sqrtf(disc);
-        float root = (-half_b - sqrtd) / a;
-        bool ok = true;
-        if (root < PT_MIN_T || closest < root) { // :159
-          root = (-half_b + sqrtd) / a;
-          if (root < PT_MIN_T || closest < root) ok = false; // :161
-        }
-        if (ok) { // ties go to the later sphere: rejection is `closest < root`
-          closest = root;
-          hit = (int)i;
-        }
+    // A lane may use the cheap conservative rejections only when nothing can overflow or be
+    // NaN: finite ray with 0 < |d|^2 < 1e6 and |o| < 1e15 in a scene whose spheres are finite
+    // and < 1e15 (checked on the host).  Every other ray takes the literal path for every
+    // discriminant that is not < 0, exactly like the shader.
+    const bool fast = A.scene_regular && (a > 1e-12f) && (a < 1e6f) &&
+                      (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
+                                       __builtin_fabsf(o.z)) < 1e15f);
+
+    // static/shader.frag:153-172 for one sphere whose discriminant is not < 0
+    auto try_candidate = [&](uint32_t idx, float half_b, float c, float disc) {
+      if (fast) {
+        // (1) origin outside the sphere (c > 0) and the sphere behind the ray (half_b >= 0):
+        //     disc <= fl(half_b^2), so sqrtd <= |half_b| and both roots are <= 0 < MIN_T.
+        // (2) origin outside, sphere ahead, and even the near root lies beyond `closest`:
+        //     q = -half_b - closest_hi*a > 0 and q^2 >= disc*(1+2^-18) imply sqrtd <= q, hence
+        //     fl(-half_b - sqrtd) >= fl(closest_hi*a) and the shader's near root (and so its
+        //     far root) exceeds closest by more than an ulp: `t_max < root` rejects both.
+        //     Both are pure rejections of candidates the literal test would also reject.
+        bool outside = c > 0.0f;
+        float q = fma_(-closest_hi, a, -half_b);
+        bool behind = half_b >= 0.0f;
+        bool beyond = (q > 0.0f) && (q * q >= disc * PT_GUARD);
+        if (outside && (behind || beyond)) return;
       }
+      float sqrtd = __builtin_sqrtf(disc);
+      float root = (-half_b - sqrtd) / a;
+      if (root < PT_MIN_T || closest < root) { // :159
+        root = (-half_b + sqrtd) / a;
+        if (root < PT_MIN_T || closest < root) return; // :161
+      }
+      // ties go to the later sphere: the rejection is `closest < root`
+      closest = root;
+      closest_hi = root * PT_GUARD;
+      hit = (int)idx;
+    };
+
+#define PT_TEST(G, HB, CC, DISC)                                  \
+  float HB, CC, DISC;                                             \
+  {                                                               \
+    V3 oc = mk(o.x - G.x, o.y - G.y, o.z - G.z);                  \
+    HB = dot3(oc, d);                                             \
+    CC = dot3(oc, oc) - G.w;                                      \
+    DISC = fma_(-a, CC, HB * HB);                                 \
+  }
+
+    // one group of four: tests, then the (rare) candidate work in list order
+#define PT_GROUP(C0, C1, C2, C3, BASE)                                            \
+  {                                                                               \
+    PT_TEST(C0, hb0, cc0, ds0)                                                    \
+    PT_TEST(C1, hb1, cc1, ds1)                                                    \
+    PT_TEST(C2, hb2, cc2, ds2)                                                    \
+    PT_TEST(C3, hb3, cc3, ds3)                                                    \
+    /* :153 `if (discriminant < 0.) return false;` - NaN falls through */         \
+    const bool m0 = alive && !(ds0 < 0.0f);                                       \
+    const bool m1 = alive && !(ds1 < 0.0f);                                       \
+    const bool m2 = alive && !(ds2 < 0.0f);                                       \
+    const bool m3 = alive && !(ds3 < 0.0f);                                       \
+    if (m0 || m1 || m2 || m3) {                                                   \
+      /* padding entries (index >= n_spheres) are never candidates */             \
+      if (m0 && (BASE) + 0u < n_spheres) try_candidate((BASE) + 0u, hb0, cc0, ds0); \
+      if (m1 && (BASE) + 1u < n_spheres) try_candidate((BASE) + 1u, hb1, cc1, ds1); \
+      if (m2 && (BASE) + 2u < n_spheres) try_candidate((BASE) + 2u, hb2, cc2, ds2); \
+      if (m3 && (BASE) + 3u < n_spheres) try_candidate((BASE) + 3u, hb3, cc3, ds3); \
+    }                                                                             \
+  }
+
+    // two register sets ping-pong (no copies): while set A is tested, set B's four
+    // ds_read_b128 are in flight, and vice versa
+    const uint32_t n_groups8 = (n_spheres + 7u) & ~7u;
+    float4 a0 = s_geom[0], a1 = s_geom[1], a2 = s_geom[2], a3 = s_geom[3];
+    for (uint32_t i = 0; i < n_groups8; i += 8) {
+      float4 b0 = s_geom[i + 4], b1 = s_geom[i + 5], b2 = s_geom[i + 6], b3 = s_geom[i + 7];
+      PT_GROUP(a0, a1, a2, a3, i)
+      a0 = s_geom[i + 8]; // the list is padded by one extra group, so this stays in bounds
+      a1 = s_geom[i + 9];
+      a2 = s_geom[i + 10];
+      a3 = s_geom[i + 11];
+      PT_GROUP(b0, b1, b2, b3, i + 4u)
     }
+#undef PT_GROUP
+#undef PT_TEST
 
     // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
     if (alive) {
