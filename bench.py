@@ -4,7 +4,9 @@
   metric   Mray/s (ray segments = hit_world invocations per second) at 1920x1080
   workload config 2: Shirley cover scene (484 spheres), 1920x1080, 50 bounces, 64-spp passes;
            the default 16 steps are exactly the config's 1024 spp "converged frame"
-  step     one pass of the hot path: one pt_render launch = 64 samples for every pixel
+  step     one pass of the hot path = 64 samples for every pixel (u_time = step index); steps are
+           enqueued `--passes-per-launch` at a time through pt_render_passes (one persistent
+           kernel launch works through all their (pixel, pass) items from one queue)
   N > 1    strong scaling: the same frame, rows dealt to ranks in interleaved 8-row bands, no
            collective while rendering, ONE all_gather of the radiance buffers (RCCL over xGMI)
            at the end of the timed region
@@ -29,11 +31,24 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_SPHERE_TEST = 20      # SURVEY.md §8d algorithmic work unit
 
 
+def usable_cores():
+    """Threads this process may actually run at once: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--passes-per-launch", type=int, default=16)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=64)
@@ -69,7 +84,8 @@ def main():
     pt = PathTracer(p.width, p.height, device=local_rank, use_torch=True)
     pt.set_spheres(sc.spheres)
     pt.set_params(p)
-    pt.reserve_passes(1)
+    ppl = max(1, min(args.passes_per_launch, max(args.steps, 1)))
+    pt.reserve_passes(ppl)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -78,11 +94,14 @@ def main():
             torch.cuda.synchronize()
 
     def run_steps(k, first_time):
-        for s in range(k):
+        done = 0
+        while done < k:
+            n = min(ppl, k - done)
             q = p.copy()
-            q.time = float(first_time + s)
+            q.time = float(first_time + done)  # pass j of this launch uses u_time = time + j
             pt.set_params(q)
-            pt.render()  # one 64-spp pass, asynchronous on torch's current stream
+            pt.render_passes(n)  # asynchronous on torch's current stream
+            done += n
 
     # warmup (untimed), then clear accumulation and statistics
     run_steps(args.warmup, 1000.0)
@@ -120,9 +139,10 @@ def main():
         flop_per_launch = FLOP_PER_SPHERE_TEST * n_sph * seg_per_launch
         achieved_tf = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         local_pix = st.local_rows * p.width
-        # algorithmic HBM bytes per launch: one 16-B slab store per pixel by the trace kernel;
-        # the fold kernel then reads slab + accum and writes accum (16 B each); scene 48 B/sphere
-        hbm_bytes = local_pix * 16 + n_sph * 48
+        # algorithmic HBM bytes per launch of the trace kernel: one 16-B slab store per
+        # (pixel, pass) item + the scene (48 B/sphere); the fold kernel's traffic is separate
+        passes_per_launch_avg = args.steps / max(st.render_launches, 1)
+        hbm_bytes = int(passes_per_launch_avg * local_pix * 16 + n_sph * 48)
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
@@ -154,7 +174,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle
 
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             strip = min(args.cpu_strip, p.width)
             x0 = (p.width - strip) // 2
             cp = sc.params.copy()
@@ -187,6 +207,7 @@ def main():
                             % (n_sph, p.width, p.height, args.max_depth, args.spp_per_step, args.steps,
                                args.spp_per_step * args.steps),
                 "partition": "%d rank(s), interleaved %d-row bands, one all_gather at frame end" % (world, band_rows),
+                "passes_per_launch": ppl,
             },
             "sec_to_converged_frame": round(wall, 4),
             "segments": int(segments),

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -52,6 +53,10 @@ struct pt_ctx {
   // read-out staging
   float4* d_resolve = nullptr;
   size_t resolve_pixels = 0;
+  // work-queue ordering feedback
+  uint32_t* d_tile_cost = nullptr;
+  uint32_t* d_tile_order = nullptr;
+  size_t tile_cap = 0;
   // counters + timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool
@@ -110,6 +115,17 @@ int ensure_buffers(pt_ctx* c) {
     c->d_slab = nullptr;
     PT_HIP(c, hipMalloc(&c->d_slab, need * sizeof(float4)));
     c->slab_pixels = need;
+  }
+  size_t tiles = (size_t)((c->width + 7) / 8) * ((c->local_rows + 7) / 8);
+  if (tiles == 0) tiles = 1;
+  if (c->tile_cap != tiles) {
+    if (c->d_tile_cost) PT_HIP(c, hipFree(c->d_tile_cost));
+    if (c->d_tile_order) PT_HIP(c, hipFree(c->d_tile_order));
+    c->d_tile_cost = nullptr; c->d_tile_order = nullptr;
+    PT_HIP(c, hipMalloc(&c->d_tile_cost, tiles * sizeof(uint32_t)));
+    PT_HIP(c, hipMalloc(&c->d_tile_order, tiles * sizeof(uint32_t)));
+    PT_HIP(c, hipMemsetAsync(c->d_tile_cost, 0, tiles * sizeof(uint32_t), c->stream));
+    c->tile_cap = tiles;
   }
   if (c->resolve_pixels < pix) {
     if (c->d_resolve) PT_HIP(c, hipFree(c->d_resolve));
@@ -203,6 +219,8 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_resolve) (void)hipFree(c->d_resolve);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+  if (c->d_tile_order) (void)hipFree(c->d_tile_order);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return PT_OK;
@@ -412,6 +430,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.mat = c->d_mat;
   A.slab = reinterpret_cast<float*>(c->d_slab);
   A.counters = c->d_counters;
+  A.tile_order = c->d_tile_order;
+  A.tile_cost = c->d_tile_cost;
 
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
   // per CU when the staged list takes most of the 160 KiB LDS
@@ -442,6 +462,10 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   auto& ev = c->events[c->events_used++];
 
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  // queue order from the previous launch's per-tile cost (identity when there is none yet)
+  hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
+                     c->d_tile_order, A.tiles_x * A.tiles_y);
+  PT_HIP(c, hipGetLastError());
   PT_HIP(c, hipEventRecord(ev.first, c->stream));
   hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
   PT_HIP(c, hipGetLastError());

@@ -35,6 +35,8 @@ struct PtKernelArgs {
   const PtMatRec* mat;        // n_spheres
   float* slab;                // n_passes * local_rows * width * float4 (rgb sum, spp)
   unsigned long long* counters;  // [0] work-queue head, [1] segments, [2] samples
+  const uint32_t* tile_order;    // n_tiles: queue position -> tile (heaviest tiles first)
+  uint32_t* tile_cost;           // n_tiles: segments traced per tile (feeds the next launch's order)
 };
 
 enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 4 };

@@ -32,7 +32,6 @@
 #define PT_MAX_T 1e5f   // static/shader.frag:5
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
-#define PT_GUARD 1.0000038f // 1 + 2^-18: guard band of the conservative candidate rejections
 
 namespace ptd {
 
@@ -183,6 +182,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
   bool alive = false;     // lane holds a live ray
   bool exhausted = false; // queue returned "no more items" to this lane
   uint32_t slab_index = 0;
+  uint32_t item_tile = 0, item_segs = 0; // cost feedback for the next launch's tile order
   int sample = 0, depth = 0;
   float seed = 0.f, st_s = 0.f, st_t = 0.f;
   V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
@@ -234,8 +234,9 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         } else {
           uint32_t item = (uint32_t)item64;
           uint32_t per_tile = 64u * A.n_passes;
-          uint32_t tile = item / per_tile;
-          uint32_t rem = item - tile * per_tile;
+          uint32_t tile_pos = item / per_tile;
+          uint32_t rem = item - tile_pos * per_tile;
+          uint32_t tile = A.tile_order[tile_pos]; // heaviest tiles are dealt first
           uint32_t pass = rem >> 6, l = rem & 63u;
           uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
           uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
@@ -254,6 +255,8 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
             st_s = (vx + 1.0f) * 0.5f; // :410
             st_t = (vy + 1.0f) * 0.5f;
             slab_index = (pass * A.local_rows + ly) * A.width + px;
+            item_tile = tile;
+            item_segs = 0;
             sum = mk(0.f, 0.f, 0.f);
             sample = 0;
             start_sample();
@@ -268,48 +271,56 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     seg_count += (uint32_t)__popcll(live);
 
     // ---- hit_world: static/shader.frag:175-196 over the LDS list -------------------------------
-    // Four spheres per trip: the next group's four ds_read_b128 are issued before the current
-    // group's arithmetic (LDS latency hides behind ~52 VALU instructions), the four
-    // discriminants are independent (ILP), and one wave-uniform branch guards the rare
-    // candidate work.  Candidates are then taken in list order, so `closest` shrinks exactly
-    // as in the shader's sequential loop.
+    //
+    // PHASE 1, scan.  Every sphere gets the cheap part of hit_sphere (:146-153: oc, half_b, c,
+    // discriminant), four spheres per trip: the next group's four ds_read_b128 are issued before
+    // the current group's arithmetic (two register sets ping-pong), the four discriminants are
+    // independent, and one wave-uniform branch guards the rare "discriminant not < 0" case.
+    // A sphere that survives is only NOTED in a small per-lane queue (16-bit indices in three
+    // VGPRs); no sqrt or division happens inside the scan.
+    //
+    // PHASE 2, exact.  Each lane pops its own candidates and runs the rest of hit_sphere
+    // (:157-164) on them with IEEE sqrt and division.  All lanes do this in lockstep, so the
+    // wave executes max-over-lanes(candidates) ~ 2-4 exact evaluations per segment instead of
+    // one per distinct (lane, sphere) pair.
+    //
+    // Why the result is the shader's, bit for bit.  For a REGULAR ray (finite, 0 < |d|^2 < 1e6,
+    // |o| < 1e15, in a scene whose spheres are finite and < 1e15 — so nothing overflows and no
+    // NaN can arise) each sphere i has a candidate value v_i that does not depend on the scan
+    // state: v_i = near root if near >= MIN_T else far root (far >= near because rounding is
+    // monotone), and the shader accepts it iff MIN_T <= v_i <= closest-so-far.  Its loop
+    // therefore returns min v_i with ties going to the largest index (:159 rejects only
+    // `t_max < root`).  Any processing order over any superset of the possible winners gives
+    // the same pair, provided ties are resolved the same way; phase 2 pops in DESCENDING index
+    // order and accepts on strict `<` (or `<=` for the very first hit, for v == MAX_T).
+    // A sphere is left out of the queue only when the shader would reject it too:
+    //   - discriminant < 0 (:153), or
+    //   - c > 0 and half_b >= 0: the origin is outside and the sphere is behind; then
+    //     disc <= fl(half_b^2), sqrtd <= |half_b|, both numerators are <= 0 and both roots
+    //     are <= 0 < MIN_T.
+    // An IRREGULAR ray (NaN/Inf/zero direction, e.g. after refract() returned vec3(0)), a lane
+    // whose queue overflows, or an irregular scene falls back to PHASE 3: the shader's loop
+    // verbatim, in ascending order, from the first sphere the queue does not cover.
     float closest = PT_MAX_T;
-    float closest_hi = PT_MAX_T * PT_GUARD; // closest * (1 + 2^-18), see try_candidate
     int hit = -1;
-    // A lane may use the cheap conservative rejections only when nothing can overflow or be
-    // NaN: finite ray with 0 < |d|^2 < 1e6 and |o| < 1e15 in a scene whose spheres are finite
-    // and < 1e15 (checked on the host).  Every other ray takes the literal path for every
-    // discriminant that is not < 0, exactly like the shader.
     const bool fast = A.scene_regular && (a > 1e-12f) && (a < 1e6f) &&
                       (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
                                        __builtin_fabsf(o.z)) < 1e15f);
+    uint32_t q0 = 0, q1 = 0, q2 = 0; // candidate queue, newest in the low half of q0
+    uint32_t q_cnt = 0;
+    uint32_t lit_from = fast ? 0xffffffffu : 0u; // first sphere index PHASE 3 must take over
 
-    // static/shader.frag:153-172 for one sphere whose discriminant is not < 0
-    auto try_candidate = [&](uint32_t idx, float half_b, float c, float disc) {
-      if (fast) {
-        // (1) origin outside the sphere (c > 0) and the sphere behind the ray (half_b >= 0):
-        //     disc <= fl(half_b^2), so sqrtd <= |half_b| and both roots are <= 0 < MIN_T.
-        // (2) origin outside, sphere ahead, and even the near root lies beyond `closest`:
-        //     q = -half_b - closest_hi*a > 0 and q^2 >= disc*(1+2^-18) imply sqrtd <= q, hence
-        //     fl(-half_b - sqrtd) >= fl(closest_hi*a) and the shader's near root (and so its
-        //     far root) exceeds closest by more than an ulp: `t_max < root` rejects both.
-        //     Both are pure rejections of candidates the literal test would also reject.
-        bool outside = c > 0.0f;
-        float q = fma_(-closest_hi, a, -half_b);
-        bool behind = half_b >= 0.0f;
-        bool beyond = (q > 0.0f) && (q * q >= disc * PT_GUARD);
-        if (outside && (behind || beyond)) return;
+    auto note_candidate = [&](uint32_t idx, float half_b, float c) {
+      if (lit_from <= idx) return; // PHASE 3 covers this sphere
+      if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
+      if (q_cnt < 6u) {
+        q2 = __builtin_amdgcn_alignbit(q2, q1, 16);
+        q1 = __builtin_amdgcn_alignbit(q1, q0, 16);
+        q0 = (q0 << 16) | idx;
+        q_cnt++;
+      } else {
+        lit_from = idx; // queue full: the literal loop continues from here
       }
-      float sqrtd = __builtin_sqrtf(disc);
-      float root = (-half_b - sqrtd) / a;
-      if (root < PT_MIN_T || closest < root) { // :159
-        root = (-half_b + sqrtd) / a;
-        if (root < PT_MIN_T || closest < root) return; // :161
-      }
-      // ties go to the later sphere: the rejection is `closest < root`
-      closest = root;
-      closest_hi = root * PT_GUARD;
-      hit = (int)idx;
     };
 
 #define PT_TEST(G, HB, CC, DISC)                                  \
@@ -321,45 +332,101 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     DISC = fma_(-a, CC, HB * HB);                                 \
   }
 
-    // one group of four: tests, then the (rare) candidate work in list order
 #define PT_GROUP(C0, C1, C2, C3, BASE)                                            \
   {                                                                               \
     PT_TEST(C0, hb0, cc0, ds0)                                                    \
     PT_TEST(C1, hb1, cc1, ds1)                                                    \
     PT_TEST(C2, hb2, cc2, ds2)                                                    \
     PT_TEST(C3, hb3, cc3, ds3)                                                    \
-    /* :153 `if (discriminant < 0.) return false;` - NaN falls through */         \
+    /* :153 `if (discriminant < 0.) return false;` */                             \
     const bool m0 = alive && !(ds0 < 0.0f);                                       \
     const bool m1 = alive && !(ds1 < 0.0f);                                       \
     const bool m2 = alive && !(ds2 < 0.0f);                                       \
     const bool m3 = alive && !(ds3 < 0.0f);                                       \
     if (m0 || m1 || m2 || m3) {                                                   \
       /* padding entries (index >= n_spheres) are never candidates */             \
-      if (m0 && (BASE) + 0u < n_spheres) try_candidate((BASE) + 0u, hb0, cc0, ds0); \
-      if (m1 && (BASE) + 1u < n_spheres) try_candidate((BASE) + 1u, hb1, cc1, ds1); \
-      if (m2 && (BASE) + 2u < n_spheres) try_candidate((BASE) + 2u, hb2, cc2, ds2); \
-      if (m3 && (BASE) + 3u < n_spheres) try_candidate((BASE) + 3u, hb3, cc3, ds3); \
+      if (m0 && (BASE) + 0u < n_spheres) note_candidate((BASE) + 0u, hb0, cc0);   \
+      if (m1 && (BASE) + 1u < n_spheres) note_candidate((BASE) + 1u, hb1, cc1);   \
+      if (m2 && (BASE) + 2u < n_spheres) note_candidate((BASE) + 2u, hb2, cc2);   \
+      if (m3 && (BASE) + 3u < n_spheres) note_candidate((BASE) + 3u, hb3, cc3);   \
     }                                                                             \
   }
 
-    // two register sets ping-pong (no copies): while set A is tested, set B's four
-    // ds_read_b128 are in flight, and vice versa
-    const uint32_t n_groups8 = (n_spheres + 7u) & ~7u;
-    float4 a0 = s_geom[0], a1 = s_geom[1], a2 = s_geom[2], a3 = s_geom[3];
-    for (uint32_t i = 0; i < n_groups8; i += 8) {
-      float4 b0 = s_geom[i + 4], b1 = s_geom[i + 5], b2 = s_geom[i + 6], b3 = s_geom[i + 7];
-      PT_GROUP(a0, a1, a2, a3, i)
-      a0 = s_geom[i + 8]; // the list is padded by one extra group, so this stays in bounds
-      a1 = s_geom[i + 9];
-      a2 = s_geom[i + 10];
-      a3 = s_geom[i + 11];
-      PT_GROUP(b0, b1, b2, b3, i + 4u)
+    {
+      const uint32_t n_groups8 = (n_spheres + 7u) & ~7u;
+      float4 a0 = s_geom[0], a1 = s_geom[1], a2 = s_geom[2], a3 = s_geom[3];
+      for (uint32_t i = 0; i < n_groups8; i += 8) {
+        float4 b0 = s_geom[i + 4], b1 = s_geom[i + 5], b2 = s_geom[i + 6], b3 = s_geom[i + 7];
+        PT_GROUP(a0, a1, a2, a3, i)
+        a0 = s_geom[i + 8]; // the list is padded by one extra group, so this stays in bounds
+        a1 = s_geom[i + 9];
+        a2 = s_geom[i + 10];
+        a3 = s_geom[i + 11];
+        PT_GROUP(b0, b1, b2, b3, i + 4u)
+      }
     }
 #undef PT_GROUP
+
+    // PHASE 2: exact evaluation of the queued candidates, newest (largest index) first
+    while (__ballot(q_cnt != 0u) != 0ull) {
+      if (q_cnt != 0u) {
+        const uint32_t idx = q0 & 0xffffu;
+        q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
+        q1 = __builtin_amdgcn_alignbit(q2, q1, 16);
+        q2 >>= 16;
+        q_cnt--;
+        const float4 g = s_geom[idx];
+        PT_TEST(g, half_b, c, disc) // bit-identical to the scan's values
+        (void)c;
+        const float sqrtd = __builtin_sqrtf(disc);
+        float v = (-half_b - sqrtd) / a;               // :158
+        if (v < PT_MIN_T) v = (-half_b + sqrtd) / a;   // :159-160 (see the note above)
+        const bool in_range = !(v < PT_MIN_T) && (v < closest || (hit < 0 && v <= closest));
+        if (in_range) {
+          closest = v;
+          hit = (int)idx;
+        }
+      }
+    }
+
+    // PHASE 3: the shader's loop verbatim for whatever the queue does not cover (rare)
+    {
+      const bool lit = alive && lit_from < n_spheres;
+      unsigned long long lit_mask = __ballot(lit);
+      if (lit_mask != 0ull) {
+        // wave-uniform start: the smallest lit_from of any lane
+        uint32_t start = lit ? lit_from : 0xffffffffu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          uint32_t other = (uint32_t)__shfl_xor((int)start, off);
+          start = other < start ? other : start;
+        }
+        start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+        for (uint32_t i = start; i < n_spheres; i++) {
+          const float4 g = s_geom[i];
+          PT_TEST(g, half_b, c, disc)
+          (void)c;
+          if (lit && i >= lit_from && !(disc < 0.0f)) { // :153 (NaN falls through)
+            const float sqrtd = __builtin_sqrtf(disc);
+            float root = (-half_b - sqrtd) / a;
+            bool ok = true;
+            if (root < PT_MIN_T || closest < root) { // :159
+              root = (-half_b + sqrtd) / a;
+              if (root < PT_MIN_T || closest < root) ok = false; // :161
+            }
+            if (ok) {
+              closest = root;
+              hit = (int)i;
+            }
+          }
+        }
+      }
+    }
 #undef PT_TEST
 
     // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
     if (alive) {
+      item_segs++;
       bool finished = false; // this camera path is over
       if (hit < 0) {
         if (A.background_mode == 0) { // background(), :289-294
@@ -454,6 +521,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         if (sample >= A.spp) {
           float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
           reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
+          atomicAdd(&A.tile_cost[item_tile], item_segs);
           alive = false;
         } else {
           start_sample();
@@ -465,6 +533,57 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
 
   if (lane == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
   (void)sample_count;
+}
+
+// --------------------------------------------------------------------------------------------
+// Work-queue order for the NEXT launch: tiles sorted by the segments they cost in the previous
+// launch, heaviest first (longest-processing-time-first), so the queue's tail is made of the
+// cheapest items (sky tiles) and the chip drains evenly.  One 1024-thread workgroup: max ->
+// 1024-bucket histogram in LDS -> scan -> scatter; then the costs are cleared.  The order only
+// affects scheduling, never results (each item writes its own slab slot).
+// --------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(1024) void pt_tile_order_kernel(uint32_t* cost, uint32_t* order,
+                                                                        uint32_t n_tiles) {
+  __shared__ uint32_t s_hist[1024];
+  __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_max;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) s_max = 0;
+  s_hist[t] = 0;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t i = t; i < n_tiles; i += 1024) m = cost[i] > m ? cost[i] : m;
+  atomicMax(&s_max, m);
+  __syncthreads();
+  const uint32_t mx = s_max;
+  if (mx == 0) { // no feedback yet: identity order
+    for (uint32_t i = t; i < n_tiles; i += 1024) order[i] = i;
+    return;
+  }
+  const float scale = 1023.0f / (float)mx;
+  for (uint32_t i = t; i < n_tiles; i += 1024) {
+    uint32_t b = 1023u - (uint32_t)((float)cost[i] * scale); // heavy -> low bucket
+    atomicAdd(&s_hist[b > 1023u ? 0u : b], 1u);
+  }
+  __syncthreads();
+  // inclusive scan (Hillis-Steele), then shift to exclusive
+  s_scan[t] = s_hist[t];
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = t >= off ? s_scan[t - off] : 0u;
+    __syncthreads();
+    s_scan[t] += v;
+    __syncthreads();
+  }
+  s_hist[t] = s_scan[t] - s_hist[t]; // exclusive start of bucket t
+  __syncthreads();
+  for (uint32_t i = t; i < n_tiles; i += 1024) {
+    uint32_t b = 1023u - (uint32_t)((float)cost[i] * scale);
+    uint32_t pos = atomicAdd(&s_hist[b > 1023u ? 0u : b], 1u);
+    order[pos] = i;
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < n_tiles; i += 1024) cost[i] = 0;
 }
 
 // --------------------------------------------------------------------------------------------

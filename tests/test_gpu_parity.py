@@ -236,6 +236,57 @@ def test_nan_and_degenerate_geometry(ora):
     t.close()
 
 
+def test_candidate_queue_overflow_falls_back_to_literal_loop(ora):
+    """More than six candidate spheres along one ray (nested + stacked spheres): the per-lane
+    queue overflows and the kernel continues with the shader's loop verbatim."""
+    sc = scenes.config1(64, 36, 4, 8)
+    items = []
+    for k in range(12):  # nested glass shells around the view axis, decreasing radius
+        items.append(((0.0, 0.0, -1.0), 0.9 - 0.05 * k, abi.PT_GLASS if k % 2 else abi.PT_DIFFUSE, 1.5))
+    for k in range(10):  # a row of spheres behind each other
+        items.append(((0.3, 0.0, -1.5 - 0.7 * k), 0.3, abi.PT_METAL, 0.0))
+    sp = np.zeros(len(items) + 1, dtype=abi.SPHERE_DTYPE)
+    sp[0] = sc.spheres[0]
+    for i, (c, r, t, ri) in enumerate(items, start=1):
+        sp[i]["center"], sp[i]["radius"], sp[i]["type"] = c, r, t
+        sp[i]["albedo"], sp[i]["refraction_index"], sp[i]["fuzz"] = (0.8, 0.7, 0.9), ri, 0.1
+    sp["uuid"] = np.arange(len(sp))
+    sc.spheres = sp
+    sc.n_passes = 2
+    t, *_ = _check_scene(ora, sc)
+    t.close()
+
+
+def test_irregular_scene_and_rays_take_the_literal_path(ora):
+    """Huge / non-finite sphere data switches the conservative rejections off for the whole
+    scene; a zero or NaN camera makes every ray irregular (|d|^2 == 0 -> NaN roots, which the
+    shader's comparisons ACCEPT as hits).  Both must still match the oracle bit for bit, NaNs included."""
+    sc = scenes.default_scene(48, 27, spp=3, max_depth=6)
+    sp = np.concatenate([sc.spheres, sc.spheres[:2]])
+    sp[9]["center"] = (1e20, 0.0, 0.0)
+    sp[9]["radius"] = 1e19
+    sp[10]["radius"] = np.float32("nan")
+    sp["uuid"] = np.arange(len(sp))
+    sc.spheres = sp
+    t, got, ref = _check_scene(ora, sc)
+    t.close()
+    sc = scenes.default_scene(40, 24, spp=2, max_depth=5)
+    for k in range(3):
+        sc.params.horizontal[k] = 0.0
+        sc.params.vertical[k] = 0.0
+        sc.params.lower_left_corner[k] = sc.params.camera_origin[k]  # direction == 0 exactly
+    t, got, ref = _check_scene(ora, sc)
+    t.close()
+    sc = scenes.default_scene(40, 24, spp=2, max_depth=5)
+    sc.params.camera_origin[1] = float("nan")
+    t, got, ref = _check_scene(ora, sc)
+    t.close()
+    sc = scenes.default_scene(40, 24, spp=2, max_depth=5)
+    sc.params.camera_origin[0] = 3e15  # finite but outside the regular range
+    t, got, ref = _check_scene(ora, sc)
+    t.close()
+
+
 def test_passes_batched_equals_separate_launches(ora):
     sc = scenes.default_scene(96, 54, spp=4, max_depth=8)
     sc.n_passes = 6
