@@ -27,6 +27,7 @@
  *       dot(a,b)   = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
  *       o + d*t    = fma(d, t, o)                                  (ray_at, shader.frag:106)
  *       mix(1,b,t) = fma(b, t, 1 - t)                              (background, :292)
+ *       |oc|^2 - r^2 = fma(oc.z,oc.z, fma(oc.y,oc.y, fma(oc.x,oc.x, -(r*r))))   (:149)
  *     and the handful of places marked "PT-SPEC fma" in the code.
  *   - pow(x,2.) = x*x (shader.frag:149,150,205; also defined for the reference's negative
  *     radii, src/state.rs:200,213); length_squared(v) = dot(v,v) instead of
@@ -219,7 +220,9 @@ static int hit_sphere(const PtSphere* sp, const ray_t* r, float t_min, float t_m
   v3 oc = vsub(r->origin, center);
   float a = dot3(r->direction, r->direction);
   float half_b = dot3(oc, r->direction);
-  float c = dot3(oc, oc) - sp->radius * sp->radius;
+  /* length_squared(oc) - pow(radius,2.) as ONE fma chain seeded with -r*r (PT-SPEC fma) */
+  float r2 = sp->radius * sp->radius;
+  float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -r2)));
   float discriminant = fmaf(-a, c, half_b * half_b); /* pow(half_b,2.) - a*c, PT-SPEC fma */
 
   if (discriminant < 0.0f) return 0;

@@ -32,6 +32,7 @@
 #define PT_MAX_T 1e5f   // static/shader.frag:5
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
+#define PT_COOP_MAX_LIVE 16 // tail mode when at most this many lanes of a wave hold a ray
 
 namespace ptd {
 
@@ -306,9 +307,70 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     const bool fast = A.scene_regular && (a > 1e-12f) && (a < 1e6f) &&
                       (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
                                        __builtin_fabsf(o.z)) < 1e15f);
+    // TAIL MODE.  When the queue is dry and only a few lanes of the wave still hold a ray, the
+    // scan above would spend a whole wave on them.  Instead the wave turns around: for each
+    // live ray in turn, its origin/direction are broadcast (v_readlane) and the 64 lanes test
+    // 64 DIFFERENT spheres per round, run the exact part on their own candidates, and a
+    // butterfly reduction picks min v with ties to the largest index — the same pair the
+    // shader's loop returns (see the note above; regular rays only).  ~n/64 rounds per ray
+    // instead of n tests: the heaviest items no longer set the launch's drain time.
+    const int n_live = (int)__popcll(live);
+    const bool coop = (n_live <= PT_COOP_MAX_LIVE) && (__ballot(alive && !fast) == 0ull);
+    if (coop) {
+      unsigned long long todo = live;
+      const uint32_t last_entry = PT_LDS_ENTRIES(n_spheres) - 1u;
+      while (todo != 0ull) {
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const float rox = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(o.x), L));
+        const float roy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(o.y), L));
+        const float roz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(o.z), L));
+        const float rdx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(d.x), L));
+        const float rdy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(d.y), L));
+        const float rdz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(d.z), L));
+        const float ra = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(a), L));
+        float best = PT_MAX_T;
+        int best_idx = -1;
+        for (uint32_t base = 0; base < n_spheres; base += 64u) {
+          const uint32_t idx = base + lane;
+          const float4 g = s_geom[idx < last_entry ? idx : last_entry];
+          // hit_sphere :146-150 with the broadcast ray (same operation order as PT_TEST)
+          const V3 oc = mk(rox - g.x, roy - g.y, roz - g.z);
+          const V3 rd = mk(rdx, rdy, rdz);
+          const float half_b = dot3(oc, rd);
+          const float c = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -g.w)));
+          const float disc = fma_(-ra, c, half_b * half_b);
+          if (idx < n_spheres && !(disc < 0.0f) && !(c > 0.0f && half_b >= 0.0f)) {
+            const float sqrtd = __builtin_sqrtf(disc);
+            float v = (-half_b - sqrtd) / ra;
+            if (v < PT_MIN_T) v = (-half_b + sqrtd) / ra;
+            if (!(v < PT_MIN_T) && v <= best) { // ascending within a lane: ties -> later sphere
+              best = v;
+              best_idx = (int)idx;
+            }
+          }
+        }
+        // lexicographic min of (v, ~idx) over the wave; v >= MIN_T > 0, so float bits order as uints
+        uint32_t k_hi = best_idx >= 0 ? f2u(best) : 0xffffffffu;
+        uint32_t k_lo = best_idx >= 0 ? 0xffffffffu - (uint32_t)best_idx : 0xffffffffu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const uint32_t o_hi = (uint32_t)__shfl_xor((int)k_hi, off);
+          const uint32_t o_lo = (uint32_t)__shfl_xor((int)k_lo, off);
+          const bool take = (o_hi < k_hi) || (o_hi == k_hi && o_lo < k_lo);
+          k_hi = take ? o_hi : k_hi;
+          k_lo = take ? o_lo : k_lo;
+        }
+        if ((int)lane == L && k_hi != 0xffffffffu) {
+          closest = u2f(k_hi);
+          hit = (int)(0xffffffffu - k_lo);
+        }
+      }
+    } else {
     uint32_t q0 = 0, q1 = 0, q2 = 0; // candidate queue, newest in the low half of q0
     uint32_t q_cnt = 0;
     uint32_t lit_from = fast ? 0xffffffffu : 0u; // first sphere index PHASE 3 must take over
+    const bool scan_lane = alive && fast;
 
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
       if (lit_from <= idx) return; // PHASE 3 covers this sphere
@@ -328,7 +390,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
   {                                                               \
     V3 oc = mk(o.x - G.x, o.y - G.y, o.z - G.z);                  \
     HB = dot3(oc, d);                                             \
-    CC = dot3(oc, oc) - G.w;                                      \
+    CC = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -G.w))); \
     DISC = fma_(-a, CC, HB * HB);                                 \
   }
 
@@ -338,12 +400,12 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     PT_TEST(C1, hb1, cc1, ds1)                                                    \
     PT_TEST(C2, hb2, cc2, ds2)                                                    \
     PT_TEST(C3, hb3, cc3, ds3)                                                    \
-    /* :153 `if (discriminant < 0.) return false;` */                             \
-    const bool m0 = alive && !(ds0 < 0.0f);                                       \
-    const bool m1 = alive && !(ds1 < 0.0f);                                       \
-    const bool m2 = alive && !(ds2 < 0.0f);                                       \
-    const bool m3 = alive && !(ds3 < 0.0f);                                       \
-    if (m0 || m1 || m2 || m3) {                                                   \
+    /* :153 `if (discriminant < 0.) return false;`  One compare per group: only regular   \
+       lanes use the scan (lit_from == 0 sends the others to PHASE 3), and a regular ray's \
+       discriminant is never NaN, so max(ds0..ds3) >= 0 <=> some ds_k is not < 0. */         \
+    const float dsmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ds0, ds1), ds2), ds3); \
+    if (scan_lane && dsmax >= 0.0f) {                                             \
+      const bool m0 = !(ds0 < 0.0f), m1 = !(ds1 < 0.0f), m2 = !(ds2 < 0.0f), m3 = !(ds3 < 0.0f); \
       /* padding entries (index >= n_spheres) are never candidates */             \
       if (m0 && (BASE) + 0u < n_spheres) note_candidate((BASE) + 0u, hb0, cc0);   \
       if (m1 && (BASE) + 1u < n_spheres) note_candidate((BASE) + 1u, hb1, cc1);   \
@@ -422,6 +484,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         }
       }
     }
+    } // !coop
 #undef PT_TEST
 
     // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
