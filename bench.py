@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-strip", type=int, default=256, help="width of the CPU baseline's column strip")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,11 +73,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     use_dist = world > 1
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+
+    def gather(t):
+        if args.backend == "gloo":  # rehearsal path: collectives on host copies
+            return ptdist.gather_rows(t.cpu(), p.height, band_rows, rank, world)
+        return ptdist.gather_rows(t, p.height, band_rows, rank, world)
 
     sc = scenes.config2(args.width, args.height, args.spp_per_step, args.steps, args.max_depth)
     p = sc.params.copy()
@@ -106,21 +119,22 @@ def main():
     # warmup (untimed), then clear accumulation and statistics
     run_steps(args.warmup, 1000.0)
     if use_dist and args.warmup:
-        ptdist.gather_rows(pt.accum_tensor, p.height, band_rows, rank, world)
+        gather(pt.accum_tensor)
     sync_all()
     pt.reset()
 
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps, 0.0)
-    full = ptdist.gather_rows(pt.accum_tensor, p.height, band_rows, rank, world) if use_dist else pt.accum_tensor
+    full = gather(pt.accum_tensor) if use_dist else pt.accum_tensor
     sync_all()
     t1 = time.perf_counter()
 
     st = pt.stats()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    cdev = "cuda" if args.backend == "nccl" else "cpu"
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
     totals = torch.tensor([float(st.segments), float(st.render_kernel_ms), float(st.render_launches)],
-                          dtype=torch.float64, device="cuda")
+                          dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         seg_all = totals[:1].clone()

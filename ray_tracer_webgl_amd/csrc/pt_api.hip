@@ -463,7 +463,6 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
   // queue order from the previous launch's per-tile cost (identity when there is none yet)
-  if (getenv("PT_NO_LPT")) PT_HIP(c, hipMemsetAsync(c->d_tile_cost, 0, c->tile_cap * sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
                      c->d_tile_order, A.tiles_x * A.tiles_y);
   PT_HIP(c, hipGetLastError());

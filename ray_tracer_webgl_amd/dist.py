@@ -39,8 +39,10 @@ def gather_rows(local, height, band_rows, rank, world, group=None):
     pad_rows = max_local_rows(height, band_rows, world)
     send = torch.zeros((pad_rows, width, 4), dtype=local.dtype, device=local.device)
     send[:rows_here] = local[:rows_here]
-    recv = torch.empty((world, pad_rows, width, 4), dtype=local.dtype, device=local.device)
+    # concatenated along dim 0: the layout every backend's all_gather_into_tensor accepts
+    recv = torch.empty((world * pad_rows, width, 4), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, pad_rows, width, 4)
     full = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
     for r in range(world):
         ys = abi.owned_rows(height, band_rows, r, world)

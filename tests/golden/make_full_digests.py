@@ -1,0 +1,29 @@
+"""Records the SHA-256 of the full config-2 frame produced by the HIP path (run on a GPU box):
+
+    python tests/golden/make_full_digests.py
+
+The digest pins the WHOLE 1920x1080x1024-spp frame across rounds; its correctness rests on the
+oracle window spot-checks and the partition / additivity properties of
+tests/test_gpu_properties.py, which hold for the same frame."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from ray_tracer_webgl_amd import scenes  # noqa: E402
+from ray_tracer_webgl_amd.tracer import render_scene  # noqa: E402
+
+sc = scenes.config2()
+t, a = render_scene(sc)
+out = {"config2_1920x1080_1024spp": {
+    "sha256": hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest(),
+    "segments": int(t.stats().segments)}}
+path = os.path.join(HERE, "full_frame_digests.json")
+if os.environ.get("GRAFT_REPO_ROOT"):
+    path = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "full_frame_digests.json")
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out))
