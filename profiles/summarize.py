@@ -50,4 +50,16 @@ for k in sorted(ctr):
         print("  FETCH_SIZE KiB %.6g -> bytes %.6g (x2 if wide coalesced: %.6g)" % (g["FETCH_SIZE"], g["FETCH_SIZE"] * 1024, g["FETCH_SIZE"] * 2048))
     if "WRITE_SIZE" in g:
         print("  WRITE_SIZE KiB %.6g -> bytes %.6g" % (g["WRITE_SIZE"], g["WRITE_SIZE"] * 1024))
+# HBM traffic of pt_trace_kernel per launch, corrected as MI355X_MICROARCH.md §HBM prescribes:
+# WRITE_SIZE (KiB) is exact for 16-B/lane stores and atomics; FETCH_SIZE (KiB) reads 1/2 of a wide
+# coalesced stream -> x2 (upper bound for this kernel's small, partly scattered reads).
+pm = out.get("pmc", {})
+if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
+    traffic = pm["WRITE_SIZE"] * 1024 + 2 * pm["FETCH_SIZE"] * 1024
+    out["pt_trace_kernel_hbm_bytes_per_launch"] = int(traffic)
+    print("  HBM traffic per launch (WRITE_SIZE + 2*FETCH_SIZE): %.4g bytes" % traffic)
+    json.dump({"pt_trace_kernel_hbm_bytes_per_launch": int(traffic),
+               "workload": "bench.py --steps 16 --warmup 16 (config 2, 16 passes per launch)",
+               "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]},
+              open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)

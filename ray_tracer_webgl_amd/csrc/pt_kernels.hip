@@ -32,6 +32,7 @@
 #define PT_MAX_T 1e5f   // static/shader.frag:5
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
+#define PT_QUEUE_CHUNK 32u   // work items reserved per global-queue atomic
 #define PT_COOP_MAX_LIVE 16 // tail mode when at most this many lanes of a wave hold a ray
 
 namespace ptd {
@@ -191,6 +192,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
   V3 col = mk(1, 1, 1), sum = mk(0, 0, 0);
 
   uint32_t seg_count = 0, sample_count = 0; // wave-uniform tallies
+  uint32_t pool_next = 0, pool_end = 0;     // wave-uniform: this wave's reserved queue items
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
   auto start_sample = [&]() {
@@ -217,21 +219,34 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
   };
 
   for (;;) {
-    // ---- refill: lanes without a ray pull work items from the global queue ---------------------
+    // ---- refill: lanes without a ray pull work items ---------------------------------------------
+    // The wave reserves PT_QUEUE_CHUNK consecutive items from the global queue with ONE atomic
+    // (a memory-side atomic moves 64 B, so per-item atomics would dominate the kernel's HBM
+    // traffic) and deals them to its lanes from a wave-uniform local pool.
     for (;;) {
       bool need = !alive && !exhausted;
       unsigned long long mask = __ballot(need);
       if (mask == 0ull) break;
-      uint32_t cnt = (uint32_t)__popcll(mask);
-      int leader = __ffsll((long long)mask) - 1;
-      unsigned long long base = 0;
-      if ((int)lane == leader) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)cnt);
-      base = __shfl(base, leader);
-      if (need) {
-        uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        unsigned long long item64 = base + rank;
-        if (item64 >= (unsigned long long)A.n_items) {
-          exhausted = true;
+      if (pool_next == pool_end) { // wave-uniform
+        unsigned long long base = 0;
+        if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)PT_QUEUE_CHUNK);
+        base = __shfl(base, 0);
+        if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
+          if (need) exhausted = true;
+          continue;
+        }
+        pool_next = (uint32_t)base;
+        unsigned long long end = base + PT_QUEUE_CHUNK;
+        pool_end = end < (unsigned long long)A.n_items ? (uint32_t)end : A.n_items;
+      }
+      const uint32_t avail = pool_end - pool_next;
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      const uint32_t pool_base = pool_next;
+      pool_next += cnt < avail ? cnt : avail;
+      if (need && rank < avail) {
+        unsigned long long item64 = (unsigned long long)pool_base + rank;
+        if (false) {
         } else {
           uint32_t item = (uint32_t)item64;
           uint32_t per_tile = 64u * A.n_passes;
