@@ -58,12 +58,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PT_LIB", LIB_PATH)  # dev: A/B another build of the same ABI
+    if not os.path.exists(path):
         raise ImportError(
             "libptrace.so not found at %s — build it with `make -C ray_tracer_webgl_amd/csrc` "
-            "(there is no CPU fallback)" % LIB_PATH
+            "(there is no CPU fallback)" % path
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res

@@ -68,6 +68,8 @@ struct pt_ctx {
   int num_cus = 256;
   int max_lds = 65536;
   std::string error;
+  unsigned long long* dbg_timeline = nullptr; // -DPT_TIMELINE dev builds
+  size_t dbg_timeline_n = 0;
 };
 
 namespace {
@@ -432,6 +434,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.counters = c->d_counters;
   A.tile_order = c->d_tile_order;
   A.tile_cost = c->d_tile_cost;
+  A.timeline = nullptr;
 
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
   // per CU when the staged list takes most of the 160 KiB LDS
@@ -441,10 +444,20 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pt_trace_kernel),
                                                          (int)block, lds));
   if (per_cu < 1) per_cu = 1;
+  { const char* e = getenv("PT_WG_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e); }
   unsigned long long want = (items + block - 1) / block;
   unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
   if (grid < 1) grid = 1;
+#ifdef PT_TIMELINE
+  {
+    static unsigned long long* tl = nullptr; static size_t tl_cap = 0;
+    size_t need_tl = (size_t)grid * (block / 64) * 8;
+    if (need_tl > tl_cap) { if (tl) (void)hipFree(tl); PT_HIP(c, hipMalloc(&tl, need_tl * 8)); tl_cap = need_tl; }
+    A.timeline = tl;
+    c->dbg_timeline = tl; c->dbg_timeline_n = need_tl;
+  }
+#endif
 
   if (c->events_used == c->events.size()) {
     if (c->events.size() >= 512) {
@@ -483,6 +496,17 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 }
 
 PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
+
+#ifdef PT_TIMELINE
+// dev builds only: copy the last launch's per-wave timeline (8 u64 per wave) to the host
+extern "C" __attribute__((visibility("default"))) long pt_debug_timeline(pt_ctx* c, unsigned long long* out, size_t cap) {
+  if (!c || !c->dbg_timeline) return -1;
+  (void)hipStreamSynchronize(c->stream);
+  size_t n = c->dbg_timeline_n < cap ? c->dbg_timeline_n : cap;
+  if (hipMemcpy(out, c->dbg_timeline, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long)n;
+}
+#endif
 
 PT_API int pt_synchronize(pt_ctx* c) {
   if (!c) return PT_ERR_INVALID;

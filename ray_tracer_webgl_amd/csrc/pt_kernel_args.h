@@ -37,6 +37,7 @@ struct PtKernelArgs {
   unsigned long long* counters;  // [0] work-queue head, [1] segments, [2] samples
   const uint32_t* tile_order;    // n_tiles: queue position -> tile (heaviest tiles first)
   uint32_t* tile_cost;           // n_tiles: segments traced per tile (feeds the next launch's order)
+  unsigned long long* timeline;  // dev builds (-DPT_TIMELINE) only: 8 u64 per wave; NULL otherwise
 };
 
 enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 4 };

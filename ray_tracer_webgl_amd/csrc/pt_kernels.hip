@@ -32,6 +32,7 @@
 #define PT_MAX_T 1e5f   // static/shader.frag:5
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
+#define PT_LONG_ITEM_SEGMENTS 384u // ~2x the mean item of config 2; see the priority note below
 #define PT_QUEUE_CHUNK 32u   // work items reserved per global-queue atomic
 #define PT_COOP_MAX_LIVE 16 // tail mode when at most this many lanes of a wave hold a ray
 
@@ -193,6 +194,10 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
 
   uint32_t seg_count = 0, sample_count = 0; // wave-uniform tallies
   uint32_t pool_next = 0, pool_end = 0;     // wave-uniform: this wave's reserved queue items
+#ifdef PT_TIMELINE
+  unsigned long long tl_start = __builtin_amdgcn_s_memrealtime(), tl_dry = 0, tl_coop = 0;
+  uint32_t tl_iters = 0, tl_coop_iters = 0, tl_dry_iters = 0;
+#endif
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
   auto start_sample = [&]() {
@@ -332,8 +337,21 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     // shader's loop returns (see the note above; regular rays only).  ~n/64 rounds per ray
     // instead of n tests: the heaviest items no longer set the launch's drain time.
     const int n_live = (int)__popcll(live);
+    // A launch cannot end before its longest (pixel, pass) stream has run its serial course,
+    // so waves carrying a long-running item get issue priority: their iterations complete
+    // sooner at no cost in total throughput (the SIMD arbitrates by priority, then age).
+    if (__ballot(alive && item_segs > PT_LONG_ITEM_SEGMENTS) != 0ull) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+#ifdef PT_TIMELINE
+    tl_iters++;
+    if (__ballot(exhausted) != 0ull) { if (!tl_dry) tl_dry = __builtin_amdgcn_s_memrealtime(); tl_dry_iters++; }
+#endif
     const bool coop = (n_live <= PT_COOP_MAX_LIVE) && (__ballot(alive && !fast) == 0ull);
     if (coop) {
+#ifdef PT_TIMELINE
+      if (!tl_coop) tl_coop = __builtin_amdgcn_s_memrealtime();
+      tl_coop_iters++;
+#endif
       unsigned long long todo = live;
       const uint32_t last_entry = PT_LDS_ENTRIES(n_spheres) - 1u;
       while (todo != 0ull) {
@@ -612,6 +630,13 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
   }
 
   if (lane == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
+#ifdef PT_TIMELINE
+  if (lane == 0 && A.timeline) {
+    unsigned long long* t = A.timeline + 8ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    t[0] = tl_start; t[1] = tl_dry; t[2] = tl_coop; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = tl_iters; t[5] = tl_dry_iters; t[6] = tl_coop_iters; t[7] = seg_count;
+  }
+#endif
   (void)sample_count;
 }
 
