@@ -408,7 +408,6 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
     const bool scan_lane = alive && fast;
 
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
-      if (lit_from <= idx) return; // PHASE 3 covers this sphere
       if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
       if (q_cnt < 6u) {
         q2 = __builtin_amdgcn_alignbit(q2, q1, 16);
@@ -416,7 +415,9 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         q0 = (q0 << 16) | idx;
         q_cnt++;
       } else {
-        lit_from = idx; // queue full: the literal loop continues from here
+        // queue full (it stays full, so nothing is pushed after this): the literal loop
+        // continues from the FIRST sphere that did not fit
+        lit_from = idx < lit_from ? idx : lit_from;
       }
     };
 
