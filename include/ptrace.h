@@ -242,6 +242,51 @@ typedef struct PtCenterHit {
 int pt_center_hit(const PtHostSphere* spheres, uint32_t n, const PtCameraIn* cam,
                   PtCenterHit* out);
 
+/* ---- the reference's State object (src/state.rs:31-94) behind an opaque handle -------------------
+ * The caller side of the boundary: camera + render bookkeeping exactly as src/state.rs keeps
+ * them (f64), so an interactive / turntable harness can drive the tracer the way src/lib.rs:65-104
+ * drives WebGL.  Pure host code, no GPU needed. */
+typedef struct pt_state pt_state;
+
+typedef struct PtStateView {
+  uint32_t width, height;
+  uint32_t samples_per_pixel, max_depth;
+  double aspect_ratio;
+  double camera_origin[3], camera_front[3], vup[3];
+  double yaw, pitch, camera_field_of_view;
+  double u[3], v[3], w[3];
+  double aperture, lens_radius, focus_distance;
+  double viewport_height, viewport_width;
+  double horizontal[3], vertical[3], lower_left_corner[3];
+  double cursor_point[3];
+  int32_t selected_object;
+  int32_t is_paused, should_average, should_render;
+  uint32_t even_odd_count, render_count, max_render_count;
+  float last_frame_weight;
+  uint32_t n_spheres;
+} PtStateView;
+
+int pt_state_create(pt_state** out, uint32_t width, uint32_t height); /* State::default :96-315 */
+int pt_state_destroy(pt_state* s);
+int pt_state_get(const pt_state* s, PtStateView* out);
+int pt_state_set_fov(pt_state* s, double fov_radians);                 /* :349-352 */
+int pt_state_set_camera_angles(pt_state* s, double yaw, double pitch); /* :354-358 */
+int pt_state_set_camera_origin(pt_state* s, const double origin[3]);
+int pt_state_set_lens(pt_state* s, double aperture, double focus_distance); /* lens_radius = aperture/2 */
+int pt_state_set_quality(pt_state* s, uint32_t samples_per_pixel, uint32_t max_depth);
+int pt_state_set_flags(pt_state* s, int is_paused, int should_average, float last_frame_weight);
+/* KeydownMap :14-28 as a bit mask: 1 w, 2 a, 4 s, 8 d, 16 space, 32 shift */
+int pt_state_set_keys(pt_state* s, uint32_t key_mask);
+int pt_state_update_position(pt_state* s, double dt_ms);      /* :411-441 (+ autofocus :453-471) */
+int pt_state_update_render_globals(pt_state* s);              /* :443-450 */
+int pt_state_resize(pt_state* s, uint32_t width, uint32_t height); /* :364-398, State half */
+int pt_state_should_render(const pt_state* s, int should_save);    /* src/lib.rs:77-82 */
+int pt_state_set_spheres(pt_state* s, const PtHostSphere* spheres, uint32_t n); /* uuids reassigned */
+int pt_state_spheres(const pt_state* s, PtSphere* out, uint32_t cap);  /* set_geometry narrowing */
+int pt_state_to_params(const pt_state* s, double now_ms, PtParams* out); /* run_setters :279-593 */
+/* dom::get_adjusted_screen_dimensions (src/dom.rs:277-291) */
+int pt_adjusted_screen_dimensions(double raw_width, double raw_height, uint32_t* w, uint32_t* h);
+
 #ifdef __cplusplus
 }
 #endif

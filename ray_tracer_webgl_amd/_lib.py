@@ -46,6 +46,24 @@ SIGNATURES = {
     "pt_set_sphere_uuids": (C.c_int, [C.POINTER(abi.PtHostSphere), C.c_uint32]),
     "pt_default_scene": (C.c_int, [C.POINTER(abi.PtHostSphere), C.c_uint32]),
     "pt_default_camera": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(abi.PtCameraIn)]),
+    "pt_state_create": (C.c_int, [C.POINTER(_vp), C.c_uint32, C.c_uint32]),
+    "pt_state_destroy": (C.c_int, [_vp]),
+    "pt_state_get": (C.c_int, [_vp, C.POINTER(abi.PtStateView)]),
+    "pt_state_set_fov": (C.c_int, [_vp, C.c_double]),
+    "pt_state_set_camera_angles": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "pt_state_set_camera_origin": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "pt_state_set_lens": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "pt_state_set_quality": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "pt_state_set_flags": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float]),
+    "pt_state_set_keys": (C.c_int, [_vp, C.c_uint32]),
+    "pt_state_update_position": (C.c_int, [_vp, C.c_double]),
+    "pt_state_update_render_globals": (C.c_int, [_vp]),
+    "pt_state_resize": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "pt_state_should_render": (C.c_int, [_vp, C.c_int]),
+    "pt_state_set_spheres": (C.c_int, [_vp, C.POINTER(abi.PtHostSphere), C.c_uint32]),
+    "pt_state_spheres": (C.c_int, [_vp, C.POINTER(abi.PtSphere), C.c_uint32]),
+    "pt_state_to_params": (C.c_int, [_vp, C.c_double, C.POINTER(abi.PtParams)]),
+    "pt_adjusted_screen_dimensions": (C.c_int, [C.c_double, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "pt_center_hit": (
         C.c_int,
         [C.POINTER(abi.PtHostSphere), C.c_uint32, C.POINTER(abi.PtCameraIn), C.POINTER(abi.PtCenterHit)],

@@ -154,6 +154,31 @@ class PtCenterHit(C.Structure):
     ]
 
 
+class PtStateView(C.Structure):
+    """Snapshot of the reference's State (src/state.rs:31-94), f64 like the original."""
+
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
+        ("aspect_ratio", C.c_double),
+        ("camera_origin", d3), ("camera_front", d3), ("vup", d3),
+        ("yaw", C.c_double), ("pitch", C.c_double), ("camera_field_of_view", C.c_double),
+        ("u", d3), ("v", d3), ("w", d3),
+        ("aperture", C.c_double), ("lens_radius", C.c_double), ("focus_distance", C.c_double),
+        ("viewport_height", C.c_double), ("viewport_width", C.c_double),
+        ("horizontal", d3), ("vertical", d3), ("lower_left_corner", d3),
+        ("cursor_point", d3),
+        ("selected_object", C.c_int32),
+        ("is_paused", C.c_int32), ("should_average", C.c_int32), ("should_render", C.c_int32),
+        ("even_odd_count", C.c_uint32), ("render_count", C.c_uint32), ("max_render_count", C.c_uint32),
+        ("last_frame_weight", C.c_float),
+        ("n_spheres", C.c_uint32),
+    ]
+
+
+KEY_W, KEY_A, KEY_S, KEY_D, KEY_SPACE, KEY_SHIFT = 1, 2, 4, 8, 16, 32
+
+
 def spheres_as_ctypes(spheres):
     """numpy SPHERE_DTYPE array (or PtSphere ctypes array) -> (PtSphere pointer, n, keepalive)."""
     if isinstance(spheres, np.ndarray):

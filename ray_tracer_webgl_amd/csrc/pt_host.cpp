@@ -2,6 +2,8 @@
 // camera derivation, the reference's built-in scene, the f32 narrowing, the f64 pick ray.
 #include "pt_host.hpp"
 
+#include <new>
+
 #define PT_API extern "C" __attribute__((visibility("default")))
 
 namespace {
@@ -160,3 +162,154 @@ PT_API uint32_t pt_local_rows(uint32_t height, uint32_t band_rows, uint32_t band
 }
 
 PT_API int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+// ---- pt_state: the reference's State behind an opaque handle ----------------------------------
+struct pt_state { pt::State s; };
+
+PT_API int pt_state_create(pt_state** out, uint32_t width, uint32_t height) {
+  if (!out || width == 0 || height == 0) return PT_ERR_INVALID;
+  pt_state* p = new (std::nothrow) pt_state();
+  if (!p) return PT_ERR_INVALID;
+  p->s = pt::State::default_for(width, height);
+  *out = p;
+  return PT_OK;
+}
+
+PT_API int pt_state_destroy(pt_state* s) {
+  if (!s) return PT_ERR_INVALID;
+  delete s;
+  return PT_OK;
+}
+
+static void put3d(double dst[3], const pt::Vec3& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+PT_API int pt_state_get(const pt_state* h, PtStateView* o) {
+  if (!h || !o) return PT_ERR_INVALID;
+  const pt::State& s = h->s;
+  o->width = s.width; o->height = s.height;
+  o->samples_per_pixel = s.samples_per_pixel; o->max_depth = s.max_depth;
+  o->aspect_ratio = s.aspect_ratio;
+  put3d(o->camera_origin, s.camera_origin); put3d(o->camera_front, s.camera_front); put3d(o->vup, s.vup);
+  o->yaw = s.yaw; o->pitch = s.pitch; o->camera_field_of_view = s.camera_field_of_view;
+  put3d(o->u, s.u); put3d(o->v, s.v); put3d(o->w, s.w);
+  o->aperture = s.aperture; o->lens_radius = s.lens_radius; o->focus_distance = s.focus_distance;
+  o->viewport_height = s.viewport_height; o->viewport_width = s.viewport_width;
+  put3d(o->horizontal, s.horizontal); put3d(o->vertical, s.vertical);
+  put3d(o->lower_left_corner, s.lower_left_corner);
+  put3d(o->cursor_point, s.cursor_point);
+  o->selected_object = s.selected_object;
+  o->is_paused = s.is_paused; o->should_average = s.should_average; o->should_render = s.should_render;
+  o->even_odd_count = s.even_odd_count; o->render_count = s.render_count;
+  o->max_render_count = s.max_render_count;
+  o->last_frame_weight = s.last_frame_weight;
+  o->n_spheres = (uint32_t)s.sphere_list.size();
+  return PT_OK;
+}
+
+PT_API int pt_state_set_fov(pt_state* h, double fov) {
+  if (!h) return PT_ERR_INVALID;
+  h->s.set_fov(fov);
+  return PT_OK;
+}
+
+PT_API int pt_state_set_camera_angles(pt_state* h, double yaw, double pitch) {
+  if (!h) return PT_ERR_INVALID;
+  h->s.set_camera_angles(yaw, pitch);
+  return PT_OK;
+}
+
+PT_API int pt_state_set_camera_origin(pt_state* h, const double origin[3]) {
+  if (!h || !origin) return PT_ERR_INVALID;
+  pt::Point p(origin[0], origin[1], origin[2]);
+  if (p != h->s.camera_origin) h->s.dirty = true;
+  h->s.camera_origin = p;
+  h->s.update_pipeline();
+  return PT_OK;
+}
+
+PT_API int pt_state_set_lens(pt_state* h, double aperture, double focus_distance) {
+  if (!h) return PT_ERR_INVALID;
+  if (aperture != h->s.aperture || focus_distance != h->s.focus_distance) h->s.dirty = true;
+  h->s.aperture = aperture;
+  h->s.lens_radius = aperture / 2.0; // src/state.rs:102
+  h->s.focus_distance = focus_distance;
+  h->s.update_pipeline();
+  return PT_OK;
+}
+
+PT_API int pt_state_set_quality(pt_state* h, uint32_t spp, uint32_t max_depth) {
+  if (!h || spp == 0 || max_depth == 0) return PT_ERR_INVALID;
+  if (spp != h->s.samples_per_pixel || max_depth != h->s.max_depth) h->s.dirty = true;
+  h->s.samples_per_pixel = spp;
+  h->s.max_depth = max_depth;
+  h->s.update_pipeline();
+  return PT_OK;
+}
+
+PT_API int pt_state_set_flags(pt_state* h, int is_paused, int should_average, float last_frame_weight) {
+  if (!h) return PT_ERR_INVALID;
+  h->s.is_paused = is_paused != 0;
+  h->s.should_average = should_average != 0;
+  h->s.last_frame_weight = last_frame_weight;
+  return PT_OK;
+}
+
+PT_API int pt_state_set_keys(pt_state* h, uint32_t m) {
+  if (!h) return PT_ERR_INVALID;
+  pt::KeydownMap& k = h->s.keydown_map;
+  k.w = m & 1u; k.a = m & 2u; k.s = m & 4u; k.d = m & 8u; k.space = m & 16u; k.shift = m & 32u;
+  return PT_OK;
+}
+
+PT_API int pt_state_update_position(pt_state* h, double dt_ms) {
+  if (!h) return PT_ERR_INVALID;
+  h->s.update_position(dt_ms);
+  return PT_OK;
+}
+
+PT_API int pt_state_update_render_globals(pt_state* h) {
+  if (!h) return PT_ERR_INVALID;
+  h->s.update_render_globals();
+  return PT_OK;
+}
+
+PT_API int pt_state_resize(pt_state* h, uint32_t w, uint32_t hh) {
+  if (!h || w == 0 || hh == 0) return PT_ERR_INVALID;
+  h->s.resize(w, hh);
+  return PT_OK;
+}
+
+PT_API int pt_state_should_render(const pt_state* h, int should_save) {
+  if (!h) return PT_ERR_INVALID;
+  return h->s.frame_should_render(should_save != 0) ? 1 : 0;
+}
+
+PT_API int pt_state_set_spheres(pt_state* h, const PtHostSphere* spheres, uint32_t n) {
+  if (!h || (!spheres && n)) return PT_ERR_INVALID;
+  h->s.sphere_list.clear();
+  for (uint32_t i = 0; i < n; i++) h->s.sphere_list.push_back(from_host(spheres[i]));
+  pt::set_sphere_uuids(h->s.sphere_list);
+  h->s.dirty = true;
+  h->s.update_pipeline();
+  return PT_OK;
+}
+
+PT_API int pt_state_spheres(const pt_state* h, PtSphere* out, uint32_t cap) {
+  if (!h) return PT_ERR_INVALID;
+  uint32_t n = (uint32_t)h->s.sphere_list.size();
+  if (out)
+    for (uint32_t i = 0; i < n && i < cap; i++) out[i] = pt::narrow(h->s.sphere_list[i]);
+  return (int)n;
+}
+
+PT_API int pt_state_to_params(const pt_state* h, double now_ms, PtParams* out) {
+  if (!h || !out) return PT_ERR_INVALID;
+  pt::to_params(h->s, now_ms, *out);
+  return PT_OK;
+}
+
+PT_API int pt_adjusted_screen_dimensions(double raw_w, double raw_h, uint32_t* w, uint32_t* hh) {
+  if (!w || !hh || !(raw_w > 0) || !(raw_h > 0)) return PT_ERR_INVALID;
+  pt::adjusted_screen_dimensions(raw_w, raw_h, *w, *hh);
+  return PT_OK;
+}

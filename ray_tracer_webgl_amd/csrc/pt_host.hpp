@@ -249,6 +249,17 @@ struct State {
     render_count = render_count + 1 < max_render_count ? render_count + 1 : max_render_count;
   }
 
+  // src/lib.rs:77-82
+  bool frame_should_render(bool should_save = false) const {
+    return (should_render && !is_paused) || (should_render && is_paused && should_save) ||
+           (should_render && is_paused && !should_save && render_count == 0);
+  }
+  // state.rs:364-398 (the State half of update_render_dimensions_to_match_window)
+  void resize(uint32_t w, uint32_t h) {
+    if (w != width || h != height) dirty = true;
+    width = w; height = h;
+    update_pipeline();
+  }
   void update_position(double dt); // state.rs:411-441, defined below
   void update_cursor_position_in_world(); // state.rs:453-471
 
@@ -303,15 +314,19 @@ inline void State::update_position(double dt) {
   update_pipeline();
 }
 
-// dom.rs:277-291: longest side capped at MAX_CANVAS_SIZE, aspect kept
-inline void adjusted_screen_dimensions(uint32_t win_w, uint32_t win_h, uint32_t& w, uint32_t& h) {
-  double ww = (double)win_w, hh = (double)win_h;
-  double longest = ww > hh ? ww : hh;
-  if (longest > (double)MAX_CANVAS_SIZE) {
-    double k = (double)MAX_CANVAS_SIZE / longest;
-    ww *= k; hh *= k;
+// dom.rs:277-291 get_adjusted_screen_dimensions, literally (including its quirk: the portrait
+// branch clamps the raw WIDTH, not the height)
+inline void adjusted_screen_dimensions(double raw_w, double raw_h, uint32_t& w, uint32_t& h) {
+  double aspect_ratio = raw_w / raw_h;
+  if (raw_w > raw_h) {
+    double adjusted_width = raw_w < (double)MAX_CANVAS_SIZE ? raw_w : (double)MAX_CANVAS_SIZE;
+    double adjusted_height = adjusted_width / aspect_ratio;
+    w = (uint32_t)adjusted_width; h = (uint32_t)adjusted_height;
+  } else {
+    double adjusted_height = raw_w < (double)MAX_CANVAS_SIZE ? raw_w : (double)MAX_CANVAS_SIZE;
+    double adjusted_width = adjusted_height * aspect_ratio;
+    w = (uint32_t)adjusted_width; h = (uint32_t)adjusted_height;
   }
-  w = (uint32_t)ww; h = (uint32_t)hh;
 }
 
 inline void put3(float dst[3], const Vec3& v) { // Vec3::to_array, math.rs:107-109

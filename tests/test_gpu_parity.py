@@ -407,3 +407,43 @@ def test_resize_and_reuse(ora):
     assert_bit_equal(a, ref_a, "before resize")
     assert_bit_equal(b, ref_b, "after resize")
     t.close()
+
+
+def test_frame_loop_reference_mode_matches_oracle_simulation(ora):
+    """The reference's rAF closure (src/lib.rs:65-104) driven headless: each frame is one fresh
+    pass at u_time = now, blended into RGBA8 ping-pong textures by the shader's render() rule.
+    The oracle simulates the same sequence (render pass -> blend with the other texture)."""
+    from ray_tracer_webgl_amd.app import FrameLoop
+
+    w, h = 96, 54
+    loop = FrameLoop(w, h, mode="reference")
+    loop.state.set_flags(is_paused=False)      # unpaused: 1 spp per frame, renders every tick
+    loop.state.set_quality(2, 8)
+    tex = [np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 4), np.uint8)]
+    spheres = loop.state.spheres()
+    for k, now in enumerate([16.0, 33.0, 50.0, 66.5, 83.0]):
+        if k == 3:
+            loop.state.set_camera_angles(-80.0, 5.0)   # camera change: render_count restarts
+        assert loop.frame(now) is True
+        v = loop.state.view()
+        p = loop.state.to_params(now)
+        acc, _ = ora.render(spheres, p, 1)
+        expect = ora.blend_rgba8(acc, p.samples_per_pixel, p, tex[(v.even_odd_count + 1) % 2])
+        assert np.array_equal(loop.canvas, expect), "frame %d" % k
+        tex[v.even_odd_count % 2] = expect
+    assert loop.state.view().render_count == 2 and loop.frames_rendered == 5
+    loop.close()
+    # linear mode: fp32 accumulation, restart on camera change
+    loop = FrameLoop(w, h, mode="linear")
+    loop.state.set_flags(is_paused=False)
+    loop.state.set_quality(3, 8)
+    for now in (1.0, 2.0, 3.0):
+        loop.frame(now)
+    assert loop.tracer.stats().total_spp == 9
+    loop.state.set_fov(1.2)
+    loop.frame(4.0)
+    assert loop.tracer.stats().total_spp == 3
+    p = loop.state.to_params(4.0)
+    acc, _ = ora.render(spheres, p, 1)
+    assert np.array_equal(loop.canvas, ora.resolve_rgba8(acc, 3, True))
+    loop.close()
