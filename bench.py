@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-strip", type=int, default=256, help="width of the CPU baseline's column strip")
+    ap.add_argument("--cpu-strip", type=int, default=960, help="width of the CPU baseline's column strip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")

@@ -459,7 +459,12 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   }
 #endif
 
-  if (c->events_used == c->events.size()) {
+  // inside a stream capture (hipGraph) nothing may synchronise and timing events are
+  // meaningless: skip the event pair, the launch sequence itself is capture-safe
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(c->stream, &cap);
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (!capturing && c->events_used == c->events.size()) {
     if (c->events.size() >= 512) {
       // pool full: drain (this synchronises, but only once per 512 launches)
       PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -472,24 +477,24 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       c->events.emplace_back(a, b);
     }
   }
-  auto& ev = c->events[c->events_used++];
+  std::pair<hipEvent_t, hipEvent_t>* ev = capturing ? nullptr : &c->events[c->events_used++];
 
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
   // queue order from the previous launch's per-tile cost (identity when there is none yet)
   hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
                      c->d_tile_order, A.tiles_x * A.tiles_y);
   PT_HIP(c, hipGetLastError());
-  PT_HIP(c, hipEventRecord(ev.first, c->stream));
+  if (ev) PT_HIP(c, hipEventRecord(ev->first, c->stream));
   hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
   PT_HIP(c, hipGetLastError());
-  PT_HIP(c, hipEventRecord(ev.second, c->stream));
+  if (ev) PT_HIP(c, hipEventRecord(ev->second, c->stream));
 
   uint32_t n_pix = c->local_rows * c->width;
   hipLaunchKernelGGL(pt_accumulate_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream,
                      c->accum, c->d_slab, n_pix, n_passes);
   PT_HIP(c, hipGetLastError());
 
-  c->launches++;
+  if (!capturing) c->launches++;
   c->total_spp += n_passes * (uint32_t)p.samples_per_pixel;
   c->samples += (uint64_t)n_pix * n_passes * (uint64_t)p.samples_per_pixel;
   return PT_OK;

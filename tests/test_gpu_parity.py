@@ -447,3 +447,39 @@ def test_frame_loop_reference_mode_matches_oracle_simulation(ora):
     acc, _ = ora.render(spheres, p, 1)
     assert np.array_equal(loop.canvas, ora.resolve_rgba8(acc, 3, True))
     loop.close()
+
+
+def test_render_is_hip_graph_capturable(ora):
+    """pt_render_passes neither allocates nor synchronises (after pt_reserve_passes), so a
+    frame can be captured into a hipGraph and replayed; each replay adds the same passes."""
+    import torch
+
+    sc = scenes.default_scene(96, 54, spp=4, max_depth=8)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t = PathTracer(96, 54, use_torch=True)   # binds the side stream as its launch stream
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.reserve_passes(2)
+        t.render_passes(2)                        # warm-up outside the capture
+        torch.cuda.current_stream().synchronize()
+        t.reset()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            t.render_passes(2)
+    g.replay()
+    torch.cuda.synchronize()
+    ref, _ = ora.render(sc.spheres, sc.params, 2)
+    got = t.accum_tensor.cpu().numpy()
+    assert_bit_equal(got[..., :3], ref[..., :3], "graph replay 1")
+    g.replay()
+    torch.cuda.synchronize()
+    got2 = t.accum_tensor.cpu().numpy()
+    # the fold is sequential fp32: ((p0 + p1) + p0) + p1
+    p0, _ = ora.render(sc.spheres, sc.params, 1)
+    q = sc.params.copy()
+    q.time = 1.0
+    p1, _ = ora.render(sc.spheres, q, 1)
+    expect = ((p0 + p1) + p0) + p1
+    assert_bit_equal(got2[..., :3], expect[..., :3], "graph replay 2 adds the same passes again")
+    t.close()
