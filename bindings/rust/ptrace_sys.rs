@@ -1,0 +1,83 @@
+// bindings/rust/ptrace_sys.rs — SOURCE-ONLY Rust FFI for libptrace.so (include/ptrace.h).
+//
+// The reference's host code is Rust (src/*.rs); this file is what replaces its `mod webgl`.
+// The build image has no Rust toolchain (no cargo/rustc, no network), so this file has never
+// been compiled here; the same ABI is exercised by the ctypes binding
+// (ray_tracer_webgl_amd/_lib.py) and by every `-m gpu` test.  Keep in sync with the header:
+// tests/test_abi.py::test_rust_binding_lists_the_render_abi checks the symbol list.
+// src/ptrace_sys.rs — FFI for libptrace.so (include/ptrace.h).  Replaces `mod webgl`.
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct PtSphere {            // == u_sphere_list[i], static/shader.frag:55-61
+    pub center: [f32; 3], pub radius: f32,
+    pub type_: i32, pub albedo: [f32; 3],
+    pub fuzz: f32, pub refraction_index: f32,
+    pub uuid: i32, pub _pad: i32,
+}
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct PtParams {            // == uniform block, static/shader.frag:79-99
+    pub width: u32, pub height: u32,
+    pub time: f32, pub samples_per_pixel: i32, pub max_depth: i32,
+    pub camera_origin: [f32; 3], pub horizontal: [f32; 3], pub vertical: [f32; 3],
+    pub lower_left_corner: [f32; 3], pub u: [f32; 3], pub v: [f32; 3],
+    pub lens_radius: f32,
+    pub render_count: i32, pub should_average: i32, pub last_frame_weight: f32,
+    pub background_mode: i32,
+    pub band_rows: u32, pub band_index: u32, pub band_count: u32,
+}
+
+#[repr(C)] pub struct PtCtx { _private: [u8; 0] }
+
+#[link(name = "ptrace")]
+extern "C" {
+    pub fn pt_create(out: *mut *mut PtCtx, device: c_int, width: u32, height: u32) -> c_int;
+    pub fn pt_destroy(ctx: *mut PtCtx) -> c_int;
+    pub fn pt_resize(ctx: *mut PtCtx, width: u32, height: u32) -> c_int;
+    pub fn pt_set_spheres(ctx: *mut PtCtx, spheres: *const PtSphere, n: u32) -> c_int;
+    pub fn pt_set_params(ctx: *mut PtCtx, params: *const PtParams) -> c_int;
+    pub fn pt_render(ctx: *mut PtCtx) -> c_int;
+    pub fn pt_render_passes(ctx: *mut PtCtx, n_passes: u32) -> c_int;
+    pub fn pt_reserve_passes(ctx: *mut PtCtx, max_passes: u32) -> c_int;
+    pub fn pt_reset_accum(ctx: *mut PtCtx) -> c_int;
+    pub fn pt_synchronize(ctx: *mut PtCtx) -> c_int;
+    pub fn pt_resolve(ctx: *mut PtCtx, rgba_out: *mut f32, gamma: c_int) -> c_int;
+    pub fn pt_resolve_rgba8(ctx: *mut PtCtx, rgba_out: *mut u8, gamma: c_int) -> c_int;
+    pub fn pt_blend_rgba8(ctx: *mut PtCtx, prev: *const u8, out: *mut u8) -> c_int;
+    pub fn pt_accum_ptr(ctx: *mut PtCtx, dev_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
+    pub fn pt_bind_accum(ctx: *mut PtCtx, dev_ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn pt_set_stream(ctx: *mut PtCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn pt_last_error(ctx: *mut PtCtx) -> *const c_char;
+    pub fn pt_abi_version() -> c_int;
+    pub fn pt_device_count() -> c_int;
+}
+
+// State -> uniforms: what Uniforms::run_setters uploads (src/webgl.rs:279-593)
+impl PtParams {
+    pub fn from_state(s: &crate::state::State, now_ms: f64) -> Self {
+        let spp = if s.is_paused { s.samples_per_pixel.max(25) } else { s.samples_per_pixel };
+        PtParams {
+            width: s.width, height: s.height, time: now_ms as f32,
+            samples_per_pixel: spp as i32, max_depth: s.max_depth as i32,
+            camera_origin: s.camera_origin.to_array(), horizontal: s.horizontal.to_array(),
+            vertical: s.vertical.to_array(), lower_left_corner: s.lower_left_corner.to_array(),
+            u: s.u.to_array(), v: s.v.to_array(), lens_radius: s.lens_radius as f32,
+            render_count: s.render_count as i32, should_average: s.should_average as i32,
+            last_frame_weight: s.last_frame_weight, background_mode: 0,
+            band_rows: 8, band_index: 0, band_count: 1,
+        }
+    }
+}
+
+// Sphere -> u_sphere_list[i]: what webgl::set_geometry uploads (src/webgl.rs:225-274)
+impl From<&crate::glsl::Sphere> for PtSphere {
+    fn from(s: &crate::glsl::Sphere) -> Self {
+        PtSphere {
+            center: s.center.to_array(), radius: s.radius as f32,
+            type_: s.material.material_type.value(), albedo: s.material.albedo.to_array(),
+            fuzz: s.material.fuzz, refraction_index: s.material.refraction_index,
+            uuid: s.uuid, _pad: 0,
+        }
+    }
+}

@@ -188,3 +188,34 @@ def test_scene_generators_are_deterministic():
     assert (c4.spheres["type"] == abi.PT_EMISSIVE).sum() == 1 and c4.params.background_mode == abi.PT_BG_BLACK
     assert scenes.config2().total_spp == 1024 and scenes.config3().total_spp == 4096
     assert scenes.config5().total_spp == 256 and scenes.config4().total_spp == 8192
+
+
+def test_rust_binding_lists_the_render_abi():
+    """bindings/rust/ptrace_sys.rs (source-only, row f4) declares every device-facing symbol of
+    the header with the same argument count."""
+    text = open(os.path.join(ROOT, "bindings", "rust", "ptrace_sys.rs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name in ["pt_create", "pt_destroy", "pt_resize", "pt_set_spheres", "pt_set_params", "pt_render",
+                 "pt_render_passes", "pt_reserve_passes", "pt_reset_accum", "pt_synchronize", "pt_resolve",
+                 "pt_resolve_rgba8", "pt_blend_rgba8", "pt_accum_ptr", "pt_bind_accum", "pt_set_stream",
+                 "pt_last_error", "pt_abi_version", "pt_device_count"]:
+        r = re.search(r"pub fn %s\(([^)]*)\)" % name, text)
+        h = re.search(r"\b%s\s*\(([^)]*)\)" % name, header)
+        assert r and h, name
+        n_rust = len([a for a in r.group(1).split(",") if a.strip()])
+        n_c = len([a for a in h.group(1).split(",") if a.strip() and a.strip() != "void"])
+        assert n_rust == n_c, "%s: %d rust args vs %d C args" % (name, n_rust, n_c)
+    # #[repr(C)] mirrors carry the same number of fields as the C structs
+    def c_fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+        n = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                n += len(decl.split(","))
+        return n
+    def rust_fields(struct):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, text, flags=re.S).group(1)
+        return len(re.findall(r"pub \w+:", body))
+    assert c_fields("PtSphere") == rust_fields("PtSphere")
+    assert c_fields("PtParams") == rust_fields("PtParams")
