@@ -146,7 +146,8 @@ int pt_destroy(pt_ctx* ctx);
 int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height);
 
 /* ---- scene + uniforms ------------------------------------------------------------------------
- * pt_set_spheres replaces webgl::set_geometry (src/webgl.rs:225-274); n is not capped at 15.
+ * pt_set_spheres replaces webgl::set_geometry (src/webgl.rs:225-274); n is not capped at 15:
+ * up to 10 232 spheres are walked from LDS, up to 65 528 from global memory (PT_ERR_CAPACITY beyond).
  * pt_set_params replaces Uniforms::run_setters (src/webgl.rs:629-633). Both copy. */
 int pt_set_spheres(pt_ctx* ctx, const PtSphere* spheres, uint32_t n);
 int pt_set_params(pt_ctx* ctx, const PtParams* params);

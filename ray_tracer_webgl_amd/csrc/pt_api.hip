@@ -240,21 +240,28 @@ PT_API int pt_set_stream(pt_ctx* c, void* hip_stream) {
 
 PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   if (!c || (!s && n)) return fail(c, PT_ERR_INVALID, "pt_set_spheres: NULL argument");
-  if (n > PT_MAX_SPHERES_LDS)
-    return fail(c, PT_ERR_CAPACITY, "pt_set_spheres: %u spheres exceed the LDS-resident list (%u)",
-                n, PT_MAX_SPHERES_LDS);
+  if (n > PT_MAX_SPHERES)
+    return fail(c, PT_ERR_CAPACITY, "pt_set_spheres: %u spheres exceed the 16-bit candidate index range (%u)",
+                n, PT_MAX_SPHERES);
   PT_HIP(c, hipSetDevice(c->device));
-  if (n > c->sphere_cap) {
+  if (n > c->sphere_cap || !c->d_geom) {
     if (c->d_geom) PT_HIP(c, hipFree(c->d_geom));
     if (c->d_mat) PT_HIP(c, hipFree(c->d_mat));
     c->d_geom = nullptr; c->d_mat = nullptr;
-    PT_HIP(c, hipMalloc(&c->d_geom, (size_t)n * 16));
-    PT_HIP(c, hipMalloc(&c->d_mat, (size_t)n * sizeof(PtMatRec)));
+    PT_HIP(c, hipMalloc(&c->d_geom, (size_t)PT_LDS_ENTRIES(n) * 16));
+    PT_HIP(c, hipMalloc(&c->d_mat, (size_t)(n ? n : 1) * sizeof(PtMatRec)));
     c->sphere_cap = n;
   }
   // split into the 16-byte geometry record the intersection loop stages into LDS and the 32-byte
   // shading record read once per closest hit
-  std::vector<float> geom((size_t)n * 4);
+  // geometry is uploaded already padded (multiple of 8 + one prefetch group, unreachable
+  // spheres beyond MAX_T) and with r*r precomputed: the fp32 multiply `pow(radius, 2.)` of
+  // static/shader.frag:149, performed here under -ffp-contract=off
+  const uint32_t n_pad = PT_LDS_ENTRIES(n);
+  std::vector<float> geom((size_t)n_pad * 4);
+  for (uint32_t i = n; i < n_pad; i++) {
+    geom[4 * i + 0] = 1e15f; geom[4 * i + 1] = 1e15f; geom[4 * i + 2] = 1e15f; geom[4 * i + 3] = 0.0f;
+  }
   std::vector<PtMatRec> mat(n);
   bool regular = true;
   for (uint32_t i = 0; i < n; i++) {
@@ -263,7 +270,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     geom[4 * i + 0] = s[i].center[0];
     geom[4 * i + 1] = s[i].center[1];
     geom[4 * i + 2] = s[i].center[2];
-    geom[4 * i + 3] = s[i].radius;
+    geom[4 * i + 3] = s[i].radius * s[i].radius;
     mat[i].albedo[0] = s[i].albedo[0];
     mat[i].albedo[1] = s[i].albedo[1];
     mat[i].albedo[2] = s[i].albedo[2];
@@ -273,10 +280,12 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     mat[i].radius = s[i].radius;
     mat[i].uuid = s[i].uuid;
   }
-  if (n) {
+  {
     // the stream may still be reading the previous scene
     PT_HIP(c, hipStreamSynchronize(c->stream));
-    PT_HIP(c, hipMemcpy(c->d_geom, geom.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_geom, geom.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice));
+  }
+  if (n) {
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n * sizeof(PtMatRec), hipMemcpyHostToDevice));
   }
   c->n_spheres = n;
@@ -438,11 +447,13 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
   // per CU when the staged list takes most of the 160 KiB LDS
-  size_t lds = (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16;
+  const bool in_lds = c->n_spheres <= PT_MAX_SPHERES_LDS && !getenv("PT_FORCE_GMEM");
+  size_t lds = in_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
   uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
+  const void* kfn = in_lds ? reinterpret_cast<const void*>(pt_trace_kernel)
+                           : reinterpret_cast<const void*>(pt_trace_kernel_gmem);
   int per_cu = 0;
-  PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pt_trace_kernel),
-                                                         (int)block, lds));
+  PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
   { const char* e = getenv("PT_WG_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e); }
   unsigned long long want = (items + block - 1) / block;
@@ -485,7 +496,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
                      c->d_tile_order, A.tiles_x * A.tiles_y);
   PT_HIP(c, hipGetLastError());
   if (ev) PT_HIP(c, hipEventRecord(ev->first, c->stream));
-  hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
+  if (in_lds) hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
+  else hipLaunchKernelGGL(pt_trace_kernel_gmem, dim3(grid), dim3(block), 0, c->stream, A);
   PT_HIP(c, hipGetLastError());
   if (ev) PT_HIP(c, hipEventRecord(ev->second, c->stream));
 

@@ -31,7 +31,7 @@ struct PtKernelArgs {
   uint32_t scene_regular;  // every sphere finite with |centre|, |radius| < 1e15 (host-checked)
   uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles over width x local_rows
   uint32_t n_items;           // tiles_x * tiles_y * n_passes * 64 work items
-  const float* geom;          // n_spheres * {cx, cy, cz, r}
+  const float* geom;          // PT_LDS_ENTRIES(n_spheres) * {cx, cy, cz, r*r}, padded with unreachable spheres
   const PtMatRec* mat;        // n_spheres
   float* slab;                // n_passes * local_rows * width * float4 (rgb sum, spp)
   unsigned long long* counters;  // [0] work-queue head, [1] segments, [2] samples
@@ -46,6 +46,8 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
 #define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
+#define PT_MAX_SPHERES 65528u      // candidate queues hold 16-bit indices; beyond the LDS list the
+                                   // scan reads the padded global copy (pt_trace_kernel_gmem)
 
 // pt_probe kinds (device-side evaluation of single PT-SPEC functions, for parity tests)
 enum {

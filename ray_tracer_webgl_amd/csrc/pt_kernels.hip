@@ -154,27 +154,26 @@ __device__ __forceinline__ float reflectance(float cosine, float ri) {
 using namespace ptd;
 
 // --------------------------------------------------------------------------------------------
-// The path-tracing kernel.  blockDim.x is a multiple of 64 (256 normally, 1024 when the staged
-// list is large and only one workgroup fits per CU); dynamic LDS = n_spheres * 16 bytes.
+// The path-tracing kernel body.
 // --------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKernelArgs A) {
+// GEOM_IN_LDS = true : the list is staged into LDS once per workgroup (every BASELINE config).
+// GEOM_IN_LDS = false: lists beyond the 160 KiB LDS (n > 10 232) are walked straight from the
+//                      padded global copy (wave-uniform addresses; L2-resident), same arithmetic.
+template <bool GEOM_IN_LDS>
+__device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   extern __shared__ float4 s_geom[];
+  const float4* __restrict__ g_geom = reinterpret_cast<const float4*>(A.geom);
 
-  // ---- stage the sphere geometry once per workgroup: (cx, cy, cz, r*r) -----------------------
-  {
-    const float4* g = reinterpret_cast<const float4*>(A.geom);
-    for (uint32_t i = threadIdx.x; i < A.n_spheres; i += blockDim.x) {
-      float4 v = g[i];
-      v.w = v.w * v.w; // pow(radius, 2.) static/shader.frag:149
-      s_geom[i] = v;
-    }
-    // pad to a multiple of 8 plus one prefetch group with a sphere that can never be hit:
-    // beyond MAX_T in every direction, so the literal range test rejects it too
+  // ---- stage the (already padded, {cx,cy,cz,r*r}) geometry once per workgroup ----------------
+  if constexpr (GEOM_IN_LDS) {
     const uint32_t n_padded = PT_LDS_ENTRIES(A.n_spheres);
-    for (uint32_t i = A.n_spheres + threadIdx.x; i < n_padded; i += blockDim.x)
-      s_geom[i] = make_float4(1e15f, 1e15f, 1e15f, 0.0f);
+    for (uint32_t i = threadIdx.x; i < n_padded; i += blockDim.x) s_geom[i] = g_geom[i];
+    __syncthreads();
   }
-  __syncthreads();
+  auto geom_at = [&](uint32_t i) -> float4 {
+    if constexpr (GEOM_IN_LDS) return s_geom[i];
+    else return g_geom[i];
+  };
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n_spheres = A.n_spheres;
@@ -368,7 +367,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         int best_idx = -1;
         for (uint32_t base = 0; base < n_spheres; base += 64u) {
           const uint32_t idx = base + lane;
-          const float4 g = s_geom[idx < last_entry ? idx : last_entry];
+          const float4 g = geom_at(idx < last_entry ? idx : last_entry);
           // hit_sphere :146-150 with the broadcast ray (same operation order as PT_TEST)
           const V3 oc = mk(rox - g.x, roy - g.y, roz - g.z);
           const V3 rd = mk(rdx, rdy, rdz);
@@ -452,14 +451,14 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
 
     {
       const uint32_t n_groups8 = (n_spheres + 7u) & ~7u;
-      float4 a0 = s_geom[0], a1 = s_geom[1], a2 = s_geom[2], a3 = s_geom[3];
+      float4 a0 = geom_at(0), a1 = geom_at(1), a2 = geom_at(2), a3 = geom_at(3);
       for (uint32_t i = 0; i < n_groups8; i += 8) {
-        float4 b0 = s_geom[i + 4], b1 = s_geom[i + 5], b2 = s_geom[i + 6], b3 = s_geom[i + 7];
+        float4 b0 = geom_at(i + 4), b1 = geom_at(i + 5), b2 = geom_at(i + 6), b3 = geom_at(i + 7);
         PT_GROUP(a0, a1, a2, a3, i)
-        a0 = s_geom[i + 8]; // the list is padded by one extra group, so this stays in bounds
-        a1 = s_geom[i + 9];
-        a2 = s_geom[i + 10];
-        a3 = s_geom[i + 11];
+        a0 = geom_at(i + 8); // the list is padded by one extra group, so this stays in bounds
+        a1 = geom_at(i + 9);
+        a2 = geom_at(i + 10);
+        a3 = geom_at(i + 11);
         PT_GROUP(b0, b1, b2, b3, i + 4u)
       }
     }
@@ -473,7 +472,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         q1 = __builtin_amdgcn_alignbit(q2, q1, 16);
         q2 >>= 16;
         q_cnt--;
-        const float4 g = s_geom[idx];
+        const float4 g = geom_at(idx);
         PT_TEST(g, half_b, c, disc) // bit-identical to the scan's values
         (void)c;
         const float sqrtd = __builtin_sqrtf(disc);
@@ -501,7 +500,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         }
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         for (uint32_t i = start; i < n_spheres; i++) {
-          const float4 g = s_geom[i];
+          const float4 g = geom_at(i);
           PT_TEST(g, half_b, c, disc)
           (void)c;
           if (lit && i >= lit_from && !(disc < 0.0f)) { // :153 (NaN falls through)
@@ -539,7 +538,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
         }
         finished = true;
       } else {
-        float4 g = s_geom[hit];
+        float4 g = geom_at((uint32_t)hit);
         const float4* mp = reinterpret_cast<const float4*>(A.mat + hit);
         float4 m0 = mp[0]; // albedo.xyz, fuzz
         float4 m1 = mp[1]; // refraction_index, type, radius, uuid
@@ -639,6 +638,17 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKerne
   }
 #endif
   (void)sample_count;
+}
+
+// blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
+// workgroup fits per CU); dynamic LDS = PT_LDS_ENTRIES(n_spheres) * 16 bytes.
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKernelArgs A) {
+  pt_trace_body<true>(A);
+}
+
+// same kernel for sphere lists that do not fit the LDS: no dynamic LDS, 256-thread workgroups
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_gmem(const PtKernelArgs A) {
+  pt_trace_body<false>(A);
 }
 
 // --------------------------------------------------------------------------------------------

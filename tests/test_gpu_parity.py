@@ -375,7 +375,7 @@ def test_error_behaviour(pt):
     assert lib.pt_render_passes(pt._ctx, 5) == abi.PT_ERR_CAPACITY  # nothing reserved beyond 1
     out = np.zeros((64, 64, 4), np.float32)
     assert lib.pt_resolve(pt._ctx, out.ctypes.data_as(C.c_void_p), 1) == abi.PT_ERR_NOT_READY
-    big = np.zeros(10241, dtype=abi.SPHERE_DTYPE)
+    big = np.zeros(65529, dtype=abi.SPHERE_DTYPE)
     ptr, n, keep = abi.spheres_as_ctypes(big)
     assert lib.pt_set_spheres(pt._ctx, ptr, n) == abi.PT_ERR_CAPACITY
     ctx = C.c_void_p()
@@ -483,3 +483,21 @@ def test_render_is_hip_graph_capturable(ora):
     expect = ((p0 + p1) + p0) + p1
     assert_bit_equal(got2[..., :3], expect[..., :3], "graph replay 2 adds the same passes again")
     t.close()
+
+
+def test_sphere_list_beyond_lds_capacity(ora):
+    """n > 10 232 spheres do not fit the 160 KiB LDS: the same kernel walks the padded global
+    copy instead (pt_trace_kernel_gmem).  Window-checked against the oracle."""
+    sc = scenes.config5(160, 90, 2, 1, 20, n=12000)
+    assert len(sc.spheres) == 12001
+    t, got, ref = _check_scene(ora, sc, window=(60, 84, 30, 46))
+    t.close()
+    import os
+    os.environ["PT_FORCE_GMEM"] = "1"  # and the global-memory walk gives the same bits on a small scene
+    try:
+        sc = scenes.default_scene(96, 54, spp=4, max_depth=8)
+        sc.n_passes = 2
+        t, got, ref = _check_scene(ora, sc)
+        t.close()
+    finally:
+        del os.environ["PT_FORCE_GMEM"]
