@@ -118,8 +118,8 @@ def main():
 
     # warmup (untimed), then clear accumulation and statistics
     run_steps(args.warmup, 1000.0)
-    if use_dist and args.warmup:
-        gather(pt.accum_tensor)
+    if use_dist:
+        gather(pt.accum_tensor)  # also sets up the RCCL channels outside the timed region
     sync_all()
     pt.reset()
 
@@ -172,6 +172,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved_tf / FP32_VALU_PEAK_TFLOPS, 4),
             "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2*FETCH_SIZE of this command)" if traffic else None,
             "avg_launch_ms": round(avg_ms, 4),
             "launches": int(st.render_launches),
             "flop_per_launch": flop_per_launch,
