@@ -75,8 +75,13 @@ class PathTracer:
 
     def set_params(self, params):
         self.params = params.copy()
+        rows = abi.local_rows(self.height, params.band_rows, params.band_index, params.band_count)
+        if self.use_torch and self.accum_tensor is not None and self.accum_tensor.shape[0] != max(rows, 1):
+            # a different row partition: give the old tensor back before the context resizes
+            self._check(self.lib.pt_bind_accum(self._ctx, None, 0))
+            self.accum_tensor = None
         self._check(self.lib.pt_set_params(self._ctx, C.byref(self.params)))
-        self.local_rows = abi.local_rows(self.height, params.band_rows, params.band_index, params.band_count)
+        self.local_rows = rows
         if self.use_torch:
             self._bind_torch_accum()
 
