@@ -117,7 +117,10 @@ def main():
             done += n
 
     # warmup (untimed), then clear accumulation and statistics
-    run_steps(args.warmup, 1000.0)
+    # (two launches at least, so PT_GEOM_AUTO has measured both geometry paths on this scene)
+    half = args.warmup // 2
+    run_steps(half, 1000.0)
+    run_steps(args.warmup - half, 1000.0 + half)
     if use_dist:
         gather(pt.accum_tensor)  # also sets up the RCCL channels outside the timed region
     sync_all()
@@ -165,7 +168,8 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": "pt_trace_kernel",
+            "kernel": "pt_trace_kernel" if st.geometry_path == abi.PT_GEOM_LDS else "pt_trace_kernel_scalar",
+            "geometry_path": abi.GEOM_NAMES.get(st.geometry_path, "?") + (" (autotuned)" if st.geometry_tuned else ""),
             "bound": "valu",
             "achieved": round(achieved_tf, 3),
             "peak": FP32_VALU_PEAK_TFLOPS,

@@ -43,6 +43,22 @@ enum {
   PT_EMISSIVE = 3, /* build extension (BASELINE config 4): emits `albedo`, absorbs the path     */
 };
 
+/* ---- how the intersection loop reads the sphere list (pt_set_option PT_OPT_GEOMETRY_PATH) ------
+ * Both walk the same padded list with the same arithmetic and give bit-identical images.
+ *   LDS    the list is staged into LDS once per workgroup, ds_read_b128 broadcasts (n <= 10 232)
+ *   SCALAR wave-uniform scalar loads (s_load_dwordx4) through the scalar cache / L2; sphere
+ *          data reaches the VALU as SGPR operands (any n up to 65 528)
+ *   AUTO   (default) the first two launches after pt_set_spheres measure one path each, the
+ *          faster one (time per camera sample) is used from then on                          */
+enum {
+  PT_GEOM_AUTO = 0,
+  PT_GEOM_LDS = 1,
+  PT_GEOM_SCALAR = 2,
+};
+enum {
+  PT_OPT_GEOMETRY_PATH = 1,
+};
+
 /* ---- background modes ----------------------------------------------------------------------- */
 enum {
   PT_BG_SKY = 0,   /* static/shader.frag:289-294 white→(0.5,0.7,1.0) gradient                   */
@@ -133,6 +149,8 @@ typedef struct PtStats {
   uint32_t total_spp;       /* samples per pixel accumulated                                    */
   uint32_t n_spheres;
   uint32_t local_rows;      /* rows held by this context (row partition)                        */
+  uint32_t geometry_path;   /* PT_GEOM_LDS / PT_GEOM_SCALAR used by the most recent launch          */
+  uint32_t geometry_tuned;  /* 1 once PT_GEOM_AUTO has measured both paths for this scene           */
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -188,6 +206,7 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
 
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 int pt_get_stats(pt_ctx* ctx, PtStats* out);
+int pt_set_option(pt_ctx* ctx, int key, int value);
 const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -25,10 +25,16 @@ ctr = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         ctr[row["Kernel_Name"]][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+main_kernel = None
+if ctr:
+    cands = [k for k in ctr if k.startswith("pt_trace")]
+    # the kernel bench.py times is the one dispatched most often (autotune trials run once each)
+    main_kernel = max(cands, key=lambda k: max(len(v) for v in ctr[k].values())) if cands else None
 for k in sorted(ctr):
     if not k.startswith("pt_trace"):
         continue
-    print("== PMC per dispatch of %s (mean over dispatches; summed over XCDs/SEs by rocprofv3)" % k)
+    print("== PMC per dispatch of %s (mean over dispatches; summed over XCDs/SEs by rocprofv3)%s" % (
+        k, "  <-- timed kernel" if k == main_kernel else ""))
     vals = {}
     for name in sorted(ctr[k]):
         per = defaultdict(float)
@@ -37,15 +43,12 @@ for k in sorted(ctr):
         mean = sum(per.values()) / max(len(per), 1)
         vals[name] = mean
         print("  %-28s %.6g" % (name, mean))
-    out["pmc"] = vals
+    if k == main_kernel:
+        out["pmc"] = vals
+        out["pmc_kernel"] = k
     g = vals
-    if "SQ_WAVE_CYCLES" in g and "SQ_ACTIVE_INST_VALU" in g:
-        print("  -- derived")
-        if g.get("SQ_BUSY_CYCLES"):
-            print("  VALU-active / busy-cycles (per SE sum)     %.3f" % (g["SQ_ACTIVE_INST_VALU"] / g["SQ_BUSY_CYCLES"]))
-        if g.get("SQ_INSTS_VALU") and g.get("SQ_THREAD_CYCLES_VALU") and g.get("SQ_ACTIVE_INST_VALU"):
-            print("  lanes active per VALU instr (of 64)        %.2f" % (g["SQ_THREAD_CYCLES_VALU"] / g["SQ_ACTIVE_INST_VALU"] / 4 * 1.0))
-        print("  VALU insts per wave                        %.4g" % (g["SQ_INSTS_VALU"] / max(g.get("SQ_WAVES", 1), 1)))
+    if "SQ_INSTS_VALU" in g and "GRBM_GUI_ACTIVE" in g:
+        print("  -- derived: cycles per VALU instruction per SIMD = %.3f" % ((g["GRBM_GUI_ACTIVE"] / 8.0) * 1024.0 / g["SQ_INSTS_VALU"]))
     if "FETCH_SIZE" in g:
         print("  FETCH_SIZE KiB %.6g -> bytes %.6g (x2 if wide coalesced: %.6g)" % (g["FETCH_SIZE"], g["FETCH_SIZE"] * 1024, g["FETCH_SIZE"] * 2048))
     if "WRITE_SIZE" in g:
@@ -58,8 +61,8 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
     traffic = pm["WRITE_SIZE"] * 1024 + 2 * pm["FETCH_SIZE"] * 1024
     out["pt_trace_kernel_hbm_bytes_per_launch"] = int(traffic)
     print("  HBM traffic per launch (WRITE_SIZE + 2*FETCH_SIZE): %.4g bytes" % traffic)
-    json.dump({"pt_trace_kernel_hbm_bytes_per_launch": int(traffic),
-               "workload": "bench.py --steps 16 --warmup 16 (config 2, 16 passes per launch)",
+    json.dump({"pt_trace_kernel_hbm_bytes_per_launch": int(traffic), "kernel": out.get("pmc_kernel"),
+               "workload": "bench.py --steps 16 --warmup 32 (config 2, 16 passes per launch; 1 LDS + 2 scalar dispatches)",
                "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]},
               open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)

@@ -28,6 +28,10 @@ PT_EMISSIVE = 3
 PT_BG_SKY = 0
 PT_BG_BLACK = 1
 
+PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR = 0, 1, 2
+PT_OPT_GEOMETRY_PATH = 1
+GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar"}
+
 f3 = C.c_float * 3
 d3 = C.c_double * 3
 
@@ -127,6 +131,8 @@ class PtStats(C.Structure):
         ("total_spp", C.c_uint32),
         ("n_spheres", C.c_uint32),
         ("local_rows", C.c_uint32),
+        ("geometry_path", C.c_uint32),
+        ("geometry_tuned", C.c_uint32),
     ]
 
 

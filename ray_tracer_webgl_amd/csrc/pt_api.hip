@@ -53,6 +53,13 @@ struct pt_ctx {
   // read-out staging
   float4* d_resolve = nullptr;
   size_t resolve_pixels = 0;
+  // geometry path (include/ptrace.h PT_GEOM_*): policy, autotune state
+  int geom_policy = PT_GEOM_AUTO;
+  int geom_tuned = 0;              // PT_GEOM_LDS / PT_GEOM_SCALAR once decided, 0 while measuring
+  int geom_last = PT_GEOM_LDS;     // path of the most recent launch
+  int trial_state = 0;             // 0: next launch tries LDS, 1: next tries SCALAR, 2: both enqueued
+  hipEvent_t trial_ev[4] = {nullptr, nullptr, nullptr, nullptr}; // LDS begin/end, SCALAR begin/end
+  double trial_samples[2] = {0.0, 0.0};
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -149,6 +156,19 @@ int fold_events(pt_ctx* c) {
   return PT_OK;
 }
 
+// PT_GEOM_AUTO: once both trial launches have finished (non-blocking query), keep the path with
+// the lower time per camera sample.  Images do not depend on the choice.
+void try_finish_tuning(pt_ctx* c) {
+  if (c->geom_tuned || c->trial_state < 2) return;
+  if (hipEventQuery(c->trial_ev[1]) != hipSuccess || hipEventQuery(c->trial_ev[3]) != hipSuccess) return;
+  float ms_lds = 0.f, ms_sc = 0.f;
+  if (hipEventElapsedTime(&ms_lds, c->trial_ev[0], c->trial_ev[1]) != hipSuccess) return;
+  if (hipEventElapsedTime(&ms_sc, c->trial_ev[2], c->trial_ev[3]) != hipSuccess) return;
+  double a = (double)ms_lds / (c->trial_samples[0] > 0 ? c->trial_samples[0] : 1.0);
+  double b = (double)ms_sc / (c->trial_samples[1] > 0 ? c->trial_samples[1] : 1.0);
+  c->geom_tuned = b < a ? PT_GEOM_SCALAR : PT_GEOM_LDS;
+}
+
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
   uint32_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -215,6 +235,7 @@ PT_API int pt_destroy(pt_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (hipEvent_t e : c->trial_ev) if (e) (void)hipEventDestroy(e);
   if (c->d_geom) (void)hipFree(c->d_geom);
   if (c->d_mat) (void)hipFree(c->d_mat);
   if (c->own_accum) (void)hipFree(c->own_accum);
@@ -289,6 +310,8 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n * sizeof(PtMatRec), hipMemcpyHostToDevice));
   }
   c->n_spheres = n;
+  c->geom_tuned = 0;  // a new scene: PT_GEOM_AUTO measures again
+  c->trial_state = 0;
   c->scene_regular = regular;
   c->have_spheres = true;
   return PT_OK;
@@ -447,11 +470,24 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
   // per CU when the staged list takes most of the 160 KiB LDS
-  const bool in_lds = c->n_spheres <= PT_MAX_SPHERES_LDS && !getenv("PT_FORCE_GMEM");
+  // which way the scan reads the list (bit-identical results either way)
+  int path = c->geom_policy;
+  int trial = -1; // 0 / 1 when this launch is an autotune measurement of LDS / SCALAR
+  if (c->n_spheres > PT_MAX_SPHERES_LDS) {
+    path = PT_GEOM_SCALAR;
+  } else if (path == PT_GEOM_AUTO) {
+    try_finish_tuning(c);
+    if (c->geom_tuned) path = c->geom_tuned;
+    else if (c->trial_state == 0) { path = PT_GEOM_LDS; trial = 0; }
+    else if (c->trial_state == 1) { path = PT_GEOM_SCALAR; trial = 1; }
+    else path = PT_GEOM_LDS; // both trials still in flight
+  }
+  const bool in_lds = path == PT_GEOM_LDS;
+  c->geom_last = path;
   size_t lds = in_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
   uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
   const void* kfn = in_lds ? reinterpret_cast<const void*>(pt_trace_kernel)
-                           : reinterpret_cast<const void*>(pt_trace_kernel_gmem);
+                           : reinterpret_cast<const void*>(pt_trace_kernel_scalar);
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
@@ -495,11 +531,22 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
                      c->d_tile_order, A.tiles_x * A.tiles_y);
   PT_HIP(c, hipGetLastError());
+  if (capturing) trial = -1;
+  if (trial >= 0) {
+    for (int k = 0; k < 2; k++)
+      if (!c->trial_ev[2 * trial + k]) PT_HIP(c, hipEventCreate(&c->trial_ev[2 * trial + k]));
+    PT_HIP(c, hipEventRecord(c->trial_ev[2 * trial], c->stream));
+  }
   if (ev) PT_HIP(c, hipEventRecord(ev->first, c->stream));
   if (in_lds) hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
-  else hipLaunchKernelGGL(pt_trace_kernel_gmem, dim3(grid), dim3(block), 0, c->stream, A);
+  else hipLaunchKernelGGL(pt_trace_kernel_scalar, dim3(grid), dim3(block), 0, c->stream, A);
   PT_HIP(c, hipGetLastError());
   if (ev) PT_HIP(c, hipEventRecord(ev->second, c->stream));
+  if (trial >= 0) {
+    PT_HIP(c, hipEventRecord(c->trial_ev[2 * trial + 1], c->stream));
+    c->trial_samples[trial] = (double)c->local_rows * c->width * n_passes * (double)p.samples_per_pixel;
+    c->trial_state = trial + 1;
+  }
 
   uint32_t n_pix = c->local_rows * c->width;
   hipLaunchKernelGGL(pt_accumulate_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream,
@@ -588,8 +635,22 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   out->render_launches = c->launches;
   out->total_spp = c->total_spp;
   out->n_spheres = c->n_spheres;
+  try_finish_tuning(c);
   out->local_rows = c->local_rows;
+  out->geometry_path = (uint32_t)c->geom_last;
+  out->geometry_tuned = c->geom_tuned ? 1u : 0u;
   return PT_OK;
+}
+
+PT_API int pt_set_option(pt_ctx* c, int key, int value) {
+  if (!c) return PT_ERR_INVALID;
+  if (key == PT_OPT_GEOMETRY_PATH) {
+    if (value != PT_GEOM_AUTO && value != PT_GEOM_LDS && value != PT_GEOM_SCALAR)
+      return fail(c, PT_ERR_INVALID, "pt_set_option: bad geometry path %d", value);
+    c->geom_policy = value;
+    return PT_OK;
+  }
+  return fail(c, PT_ERR_INVALID, "pt_set_option: unknown key %d", key);
 }
 
 // Device-side evaluation of single PT-SPEC functions (parity tests; see pt_kernel_args.h).

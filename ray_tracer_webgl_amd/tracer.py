@@ -93,6 +93,10 @@ class PathTracer:
             nbytes = self.accum_tensor.numel() * 4
             self._check(self.lib.pt_bind_accum(self._ctx, C.c_void_p(self.accum_tensor.data_ptr()), nbytes))
 
+    def set_geometry_path(self, path):
+        """abi.PT_GEOM_AUTO (default: measure both once per scene) / PT_GEOM_LDS / PT_GEOM_SCALAR."""
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_GEOMETRY_PATH, int(path)))
+
     def reserve_passes(self, n):
         self._check(self.lib.pt_reserve_passes(self._ctx, int(n)))
 
@@ -174,12 +178,14 @@ def _hip():
     return _hip_lib
 
 
-def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=None):
+def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=None, geometry_path=None):
     """Render a scenes.Scene completely; returns (PathTracer, accum ndarray)."""
     p = scene.params.copy()
     if band is not None:
         p.band_rows, p.band_index, p.band_count = band
     pt = PathTracer(p.width, p.height, device=device, use_torch=use_torch)
+    if geometry_path is not None:
+        pt.set_geometry_path(geometry_path)
     pt.set_spheres(scene.spheres)
     pt.set_params(p)
     per = passes_per_launch or scene.n_passes

@@ -486,18 +486,30 @@ def test_render_is_hip_graph_capturable(ora):
 
 
 def test_sphere_list_beyond_lds_capacity(ora):
-    """n > 10 232 spheres do not fit the 160 KiB LDS: the same kernel walks the padded global
-    copy instead (pt_trace_kernel_gmem).  Window-checked against the oracle."""
+    """n > 10 232 spheres do not fit the 160 KiB LDS: the scalar-load walk of the padded
+    global copy (pt_trace_kernel_scalar) is used instead.  Window-checked against the oracle."""
     sc = scenes.config5(160, 90, 2, 1, 20, n=12000)
     assert len(sc.spheres) == 12001
     t, got, ref = _check_scene(ora, sc, window=(60, 84, 30, 46))
+    assert t.stats().geometry_path == abi.PT_GEOM_SCALAR
     t.close()
-    import os
-    os.environ["PT_FORCE_GMEM"] = "1"  # and the global-memory walk gives the same bits on a small scene
-    try:
-        sc = scenes.default_scene(96, 54, spp=4, max_depth=8)
-        sc.n_passes = 2
-        t, got, ref = _check_scene(ora, sc)
+
+
+@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_AUTO])
+def test_geometry_paths_are_bit_identical(ora, path):
+    """LDS walk, scalar-load walk and the autotuned choice give the same bits (and the same
+    segment counts) on scenes that exercise every phase of hit_world."""
+    for sc in (scenes.default_scene(96, 54, spp=4, max_depth=8), scenes.config2(96, 54, 4, 2, 50),
+               scenes.config4(48, 48, 4, 2, 50)):
+        sc.n_passes = 4
+        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 4 launches: AUTO tries both
+        ref, seg = ora.render(sc.spheres, sc.params, 4)
+        assert_bit_equal(got, ref, "%s path %d" % (sc.name, path))
+        st = t.stats()
+        assert st.segments == seg
+        if path != abi.PT_GEOM_AUTO:
+            assert st.geometry_path == path
+        else:
+            assert st.geometry_tuned == 1 and st.geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR)
         t.close()
-    finally:
-        del os.environ["PT_FORCE_GMEM"]
+    assert t.lib.pt_set_option(None, 1, 1) == abi.PT_ERR_INVALID
