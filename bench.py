@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--passes-per-launch", type=int, default=16)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -117,10 +117,15 @@ def main():
             done += n
 
     # warmup (untimed), then clear accumulation and statistics
-    # (two launches at least, so PT_GEOM_AUTO has measured both geometry paths on this scene)
-    half = args.warmup // 2
-    run_steps(half, 1000.0)
-    run_steps(args.warmup - half, 1000.0 + half)
+    # split into three launches when possible: PT_GEOM_AUTO runs one cold launch, then measures
+    # each geometry path once on equal-sized launches (images do not depend on the choice)
+    third = args.warmup // 3
+    if third >= 1:
+        run_steps(args.warmup - 2 * third, 1000.0)
+        run_steps(third, 2000.0)
+        run_steps(third, 3000.0)
+    else:
+        run_steps(args.warmup, 1000.0)
     if use_dist:
         gather(pt.accum_tensor)  # also sets up the RCCL channels outside the timed region
     sync_all()

@@ -48,8 +48,9 @@ enum {
  *   LDS    the list is staged into LDS once per workgroup, ds_read_b128 broadcasts (n <= 10 232)
  *   SCALAR wave-uniform scalar loads (s_load_dwordx4) through the scalar cache / L2; sphere
  *          data reaches the VALU as SGPR operands (any n up to 65 528)
- *   AUTO   (default) the first two launches after pt_set_spheres measure one path each, the
- *          faster one (time per camera sample) is used from then on                          */
+ *   AUTO   (default) after pt_set_spheres the first launch runs cold (LDS, unmeasured), the
+ *          second and third measure one path each, and the faster one (time per camera
+ *          sample) is used from then on                                                     */
 enum {
   PT_GEOM_AUTO = 0,
   PT_GEOM_LDS = 1,

@@ -57,7 +57,8 @@ struct pt_ctx {
   int geom_policy = PT_GEOM_AUTO;
   int geom_tuned = 0;              // PT_GEOM_LDS / PT_GEOM_SCALAR once decided, 0 while measuring
   int geom_last = PT_GEOM_LDS;     // path of the most recent launch
-  int trial_state = 0;             // 0: next launch tries LDS, 1: next tries SCALAR, 2: both enqueued
+  int trial_state = 0;             // 0: unmeasured first launch (cold), 1: next measures LDS,
+                                   // 2: next measures SCALAR, 3: both enqueued
   hipEvent_t trial_ev[4] = {nullptr, nullptr, nullptr, nullptr}; // LDS begin/end, SCALAR begin/end
   double trial_samples[2] = {0.0, 0.0};
   // work-queue ordering feedback
@@ -159,7 +160,7 @@ int fold_events(pt_ctx* c) {
 // PT_GEOM_AUTO: once both trial launches have finished (non-blocking query), keep the path with
 // the lower time per camera sample.  Images do not depend on the choice.
 void try_finish_tuning(pt_ctx* c) {
-  if (c->geom_tuned || c->trial_state < 2) return;
+  if (c->geom_tuned || c->trial_state < 3) return;
   if (hipEventQuery(c->trial_ev[1]) != hipSuccess || hipEventQuery(c->trial_ev[3]) != hipSuccess) return;
   float ms_lds = 0.f, ms_sc = 0.f;
   if (hipEventElapsedTime(&ms_lds, c->trial_ev[0], c->trial_ev[1]) != hipSuccess) return;
@@ -478,8 +479,9 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   } else if (path == PT_GEOM_AUTO) {
     try_finish_tuning(c);
     if (c->geom_tuned) path = c->geom_tuned;
-    else if (c->trial_state == 0) { path = PT_GEOM_LDS; trial = 0; }
-    else if (c->trial_state == 1) { path = PT_GEOM_SCALAR; trial = 1; }
+    else if (c->trial_state == 0) { path = PT_GEOM_LDS; c->trial_state = 1; } // cold launch: not measured
+    else if (c->trial_state == 1) { path = PT_GEOM_LDS; trial = 0; }
+    else if (c->trial_state == 2) { path = PT_GEOM_SCALAR; trial = 1; }
     else path = PT_GEOM_LDS; // both trials still in flight
   }
   const bool in_lds = path == PT_GEOM_LDS;
@@ -545,7 +547,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   if (trial >= 0) {
     PT_HIP(c, hipEventRecord(c->trial_ev[2 * trial + 1], c->stream));
     c->trial_samples[trial] = (double)c->local_rows * c->width * n_passes * (double)p.samples_per_pixel;
-    c->trial_state = trial + 1;
+    c->trial_state = trial + 2;
   }
 
   uint32_t n_pix = c->local_rows * c->width;

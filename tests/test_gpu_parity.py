@@ -501,9 +501,9 @@ def test_geometry_paths_are_bit_identical(ora, path):
     segment counts) on scenes that exercise every phase of hit_world."""
     for sc in (scenes.default_scene(96, 54, spp=4, max_depth=8), scenes.config2(96, 54, 4, 2, 50),
                scenes.config4(48, 48, 4, 2, 50)):
-        sc.n_passes = 4
-        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 4 launches: AUTO tries both
-        ref, seg = ora.render(sc.spheres, sc.params, 4)
+        sc.n_passes = 5
+        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 5 launches: AUTO tries both
+        ref, seg = ora.render(sc.spheres, sc.params, 5)
         assert_bit_equal(got, ref, "%s path %d" % (sc.name, path))
         st = t.stats()
         assert st.segments == seg
