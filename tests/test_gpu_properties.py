@@ -123,3 +123,15 @@ def test_default_scene_reference_resolution(ora):
     spot_check(ora, sc, a, (600, 616, 340, 350))
     spot_check(ora, sc, a, (300, 310, 250, 258))  # the negative-radius metal spheres
     t.close()
+
+
+def test_config2_full_resolution_whole_frame_vs_oracle(ora):
+    """Every one of the 1920x1080 pixels of the cover scene against the oracle (2 passes x 8 spp,
+    depth 50: the oracle needs a few seconds on the box's cores)."""
+    sc = scenes.config2(1920, 1080, 8, 2, 50)
+    t, a = render_scene(sc)
+    ref, seg = ora.render(sc.spheres, sc.params, 2)
+    g, r = bits(a), bits(ref)
+    assert np.array_equal(g, r), "%d of %d values differ" % ((g != r).sum(), g.size)
+    assert t.stats().segments == seg
+    t.close()

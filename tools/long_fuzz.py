@@ -1,0 +1,28 @@
+"""Dev tool: many more seeds of tests/test_gpu_fuzz.py's generator than the suite runs."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from oracle import oracle
+from ray_tracer_webgl_amd.tracer import render_scene
+from test_gpu_fuzz import random_scene
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for seed in range(lo, hi):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 5, 9, 17, 40, 130, 400]))
+    width, height = int(rng.integers(9, 200)), int(rng.integers(5, 120))
+    spp, depth, passes = int(rng.integers(1, 9)), int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 5))
+    sc = random_scene(rng, n, width, height, spp, depth, passes)
+    path = int(rng.integers(0, 3))
+    t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=path)
+    ref, seg = oracle.render(sc.spheres, sc.params, passes)
+    ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and t.stats().segments == seg
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, n, width, height, spp, depth, passes, path, flush=True)
+    t.close()
+    if seed % 50 == 0:
+        print("seed", seed, "ok so far, bad =", bad, flush=True)
+print("done", lo, hi, "bad =", bad)
