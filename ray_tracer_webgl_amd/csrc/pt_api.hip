@@ -493,7 +493,6 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
-  { const char* e = getenv("PT_WG_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e); }
   unsigned long long want = (items + block - 1) / block;
   unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
