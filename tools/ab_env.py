@@ -13,6 +13,8 @@ pt = PathTracer(1920, 1080)
 pt.set_spheres(sc.spheres)
 pt.set_params(sc.params)
 pt.reserve_passes(16)
+if os.environ.get('PT_GEOM'):
+    pt.set_geometry_path(int(os.environ['PT_GEOM']))
 for n in plist:
     res = {v: [] for v in vals}
     for rep in range(3):
