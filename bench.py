@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--passes-per-launch", type=int, default=16)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -99,6 +99,9 @@ def main():
     pt.set_params(p)
     ppl = max(1, min(args.passes_per_launch, max(args.steps, 1)))
     pt.reserve_passes(ppl)
+    # set-up, like reserving the workspace: settle how the scan reads the sphere list (LDS walk
+    # or scalar-load walk, bit-identical images) by measuring both once on this scene
+    pt.tune(ppl)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -117,15 +120,7 @@ def main():
             done += n
 
     # warmup (untimed), then clear accumulation and statistics
-    # split into three launches when possible: PT_GEOM_AUTO runs one cold launch, then measures
-    # each geometry path once on equal-sized launches (images do not depend on the choice)
-    third = args.warmup // 3
-    if third >= 1:
-        run_steps(args.warmup - 2 * third, 1000.0)
-        run_steps(third, 2000.0)
-        run_steps(third, 3000.0)
-    else:
-        run_steps(args.warmup, 1000.0)
+    run_steps(args.warmup, 1000.0)
     if use_dist:
         gather(pt.accum_tensor)  # also sets up the RCCL channels outside the timed region
     sync_all()

@@ -208,6 +208,10 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 int pt_get_stats(pt_ctx* ctx, PtStats* out);
 int pt_set_option(pt_ctx* ctx, int key, int value);
+/* Settles PT_GEOM_AUTO now instead of lazily: renders n_passes passes three times with the
+ * current scene and uniforms (cold, LDS, scalar), keeps the faster path, then clears the
+ * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes. */
+int pt_tune(pt_ctx* ctx, uint32_t n_passes);
 const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -654,6 +654,21 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   return fail(c, PT_ERR_INVALID, "pt_set_option: unknown key %d", key);
 }
 
+PT_API int pt_tune(pt_ctx* c, uint32_t n_passes) {
+  if (!c || n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_tune: bad argument");
+  if (c->geom_policy != PT_GEOM_AUTO || c->n_spheres > PT_MAX_SPHERES_LDS) return PT_OK; // nothing to decide
+  c->geom_tuned = 0;
+  c->trial_state = 0;
+  for (int k = 0; k < 3; k++) {
+    int rc = pt_render_passes(c, n_passes);
+    if (rc != PT_OK) return rc;
+  }
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  try_finish_tuning(c);
+  return pt_reset_accum(c);
+}
+
 // Device-side evaluation of single PT-SPEC functions (parity tests; see pt_kernel_args.h).
 // `in`/`out` are HOST pointers; counts are in floats.
 PT_API int pt_probe(pt_ctx* c, int kind, const float* in, size_t n_in, float* out, size_t n_out,

@@ -97,6 +97,12 @@ class PathTracer:
         """abi.PT_GEOM_AUTO (default: measure both once per scene) / PT_GEOM_LDS / PT_GEOM_SCALAR."""
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_GEOMETRY_PATH, int(path)))
 
+    def tune(self, n_passes):
+        """Settle PT_GEOM_AUTO now (three untimed launches of n_passes passes); clears the accumulation."""
+        self._check(self.lib.pt_tune(self._ctx, int(n_passes)))
+        if self.accum_tensor is not None:
+            self.accum_tensor.zero_()
+
     def reserve_passes(self, n):
         self._check(self.lib.pt_reserve_passes(self._ctx, int(n)))
 

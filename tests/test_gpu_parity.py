@@ -513,3 +513,19 @@ def test_geometry_paths_are_bit_identical(ora, path):
             assert st.geometry_tuned == 1 and st.geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR)
         t.close()
     assert t.lib.pt_set_option(None, 1, 1) == abi.PT_ERR_INVALID
+
+
+def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):
+    sc = scenes.config2(128, 72, 4, 2, 50)
+    t = PathTracer(128, 72)
+    t.set_spheres(sc.spheres)
+    t.set_params(sc.params)
+    t.reserve_passes(2)
+    t.tune(2)
+    st = t.stats()
+    assert st.geometry_tuned == 1 and st.total_spp == 0 and st.segments == 0
+    t.render_passes(2)
+    ref, seg = ora.render(sc.spheres, sc.params, 2)
+    assert_bit_equal(t.accum(), ref, "after pt_tune")
+    assert t.stats().segments == seg and t.stats().geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR)
+    t.close()
