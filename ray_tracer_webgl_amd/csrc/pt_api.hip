@@ -629,6 +629,9 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   unsigned long long ctr[PT_CTR_COUNT];
   PT_HIP(c, hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
   memset(out, 0, sizeof *out);
+#ifdef PT_TIMELINE
+  fprintf(stderr, "TIMELINE iters %llu phase3_entries %llu phase3_spheres %llu phase2_iters %llu overflow_lanes %llu\n", ctr[3], ctr[4], ctr[5], ctr[6], ctr[7]);
+#endif
   out->segments = ctr[PT_CTR_SEGMENTS];
   out->samples = c->samples;
   out->sphere_tests = ctr[PT_CTR_SEGMENTS] * (uint64_t)c->n_spheres;

@@ -210,6 +210,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 #ifdef PT_TIMELINE
   unsigned long long tl_start = __builtin_amdgcn_s_memrealtime(), tl_dry = 0, tl_coop = 0;
   uint32_t tl_iters = 0, tl_coop_iters = 0, tl_dry_iters = 0;
+  unsigned long long tl_p3_entries = 0, tl_p3_spheres = 0, tl_p2_iters = 0, tl_ovf_lanes = 0;
 #endif
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
@@ -480,6 +481,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
     // PHASE 2: exact evaluation of the queued candidates, newest (largest index) first
     while (__ballot(q_cnt != 0u) != 0ull) {
+#ifdef PT_TIMELINE
+      tl_p2_iters++;
+#endif
       if (q_cnt != 0u) {
         const uint32_t idx = q0 & 0xffffu;
         q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
@@ -513,6 +517,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           start = other < start ? other : start;
         }
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+#ifdef PT_TIMELINE
+        tl_p3_entries++; tl_p3_spheres += n_spheres - start; tl_ovf_lanes += __popcll(lit_mask);
+#endif
         for (uint32_t i = start; i < n_spheres; i++) {
           const float4 g = geom_at(i);
           PT_TEST(g, half_b, c, disc)
@@ -649,6 +656,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     unsigned long long* t = A.timeline + 8ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     t[0] = tl_start; t[1] = tl_dry; t[2] = tl_coop; t[3] = __builtin_amdgcn_s_memrealtime();
     t[4] = tl_iters; t[5] = tl_dry_iters; t[6] = tl_coop_iters; t[7] = seg_count;
+    atomicAdd(&A.counters[4], tl_p3_entries); atomicAdd(&A.counters[5], tl_p3_spheres); atomicAdd(&A.counters[6], tl_p2_iters); atomicAdd(&A.counters[7], tl_ovf_lanes); atomicAdd(&A.counters[3], (unsigned long long)tl_iters);
   }
 #endif
   (void)sample_count;

@@ -30,3 +30,4 @@ print("iterations/wave: total p50 %.0f max %.0f | after queue dry p50 %.0f max %
 busy = (end - 0).sum() / (len(t) * end.max())
 print("mean wave lifetime / kernel span = %.3f ; time in scan-mode after dry (mean) %.0f us ; in tail mode %.0f us" % (
     busy, (coop - dry).mean(), (end - coop).mean()))
+pt.stats()
