@@ -529,3 +529,22 @@ def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):
     assert_bit_equal(t.accum(), ref, "after pt_tune")
     assert t.stats().segments == seg and t.stats().geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR)
     t.close()
+
+
+def test_plain_c_example_matches_python_path(tmp_path):
+    """examples/render.c drives the same ABI from plain C (no Python/torch in the process): its
+    PPM must equal the frame the ctypes path resolves for the same calls."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    out = str(tmp_path / "c.ppm")
+    subprocess.check_call([os.path.join(root, "examples", "render"), out, "160", "88", "3"])
+    data = open(out, "rb").read()
+    header, pix = data.split(b"255\n", 1)
+    img = np.frombuffer(pix, dtype=np.uint8).reshape(88, 160, 3)[::-1]
+    sc = scenes.default_scene(160, 88, spp=25, max_depth=8)
+    sc.n_passes = 3
+    t, _ = render_scene(sc)
+    assert np.array_equal(t.resolve_rgba8(True)[..., :3], img)
+    t.close()
