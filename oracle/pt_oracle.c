@@ -16,8 +16,11 @@
  * (src/webgl.rs:320-331).  This oracle is therefore pinned only by (a) an independent numpy
  * restatement of the integer hash (tests/test_oracle_kat.py), (b) hand-derived known-answer
  * cases for intersection / scatter, (c) the f64 Sphere::hit of src/glsl.rs:42-82 restated in
- * ora_center_hit_f64, and (d) the committed fixtures under tests/golden/, which this oracle
- * itself generated (tests/golden/make_golden.py).
+ * ora_center_hit_f64, (d) the committed fixtures under tests/golden/, which this oracle
+ * itself generated (tests/golden/make_golden.py), and (e) for the deterministic part of the path
+ * (camera, pixel mapping, background, gamma) 43 sky pixels of the reference's own published
+ * screenshot of State::default, matched to +-1.5/255 (tests/golden/reference_sky_pixels.json).
+ * The Monte-Carlo part (RNG use, scatter, accumulation) remains unpinned.
  *
  * ARITHMETIC CONTRACT ("PT-SPEC").  GLSL leaves operation order, fusion and
  * built-in precision to the driver, so a bit-reproducible restatement has to pin them:

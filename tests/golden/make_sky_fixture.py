@@ -1,0 +1,90 @@
+"""Extracts a few dozen SKY pixels of the reference's own screenshot of State::default
+(/root/reference/images/14.png, 1280x702 RGBA8; SURVEY.md §2 "Gallery") into a small JSON fixture.
+
+Sky pixels carry no Monte-Carlo noise and no material: their value is
+sqrt(mix(white, (0.5,0.7,1.0), 0.5*(normalize(d).y+1))) for the camera ray through that pixel, so
+they pin — against the reference's real output — the camera derivation (src/state.rs:98-125), the
+pixel -> v_position -> st mapping and row orientation (static/shader.vert:8, shader.frag:410),
+background() (:289-294) and the sqrt gamma (:380).  Only pixel VALUES are stored (data), not the
+image.  Run where /root/reference exists:  python tests/golden/make_sky_fixture.py
+"""
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = "/root/reference/images/14.png"
+
+
+def read_png(path):
+    d = open(path, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat = 8, b""
+    while pos < len(d):
+        (ln,) = struct.unpack(">I", d[pos:pos + 4])
+        typ, dat = d[pos + 4:pos + 8], d[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+        if typ == b"IHDR":
+            w, h, bd, ct, _, _, il = struct.unpack(">IIBBBBB", dat)
+        elif typ == b"IDAT":
+            idat += dat
+    assert bd == 8 and il == 0
+    ch = {2: 3, 6: 4}[ct]
+    raw = zlib.decompress(idat)
+    stride = w * ch
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    p = 0
+    for y in range(h):
+        f = raw[p]
+        line = np.frombuffer(raw[p + 1:p + 1 + stride], np.uint8).astype(np.int32)
+        p += 1 + stride
+        cur = line.copy()
+        if f == 1:
+            for i in range(ch, stride):
+                cur[i] = (cur[i] + cur[i - ch]) & 255
+        elif f == 2:
+            cur = (line + prev) & 255
+        elif f == 3:
+            for i in range(stride):
+                a = cur[i - ch] if i >= ch else 0
+                cur[i] = (cur[i] + ((a + prev[i]) >> 1)) & 255
+        elif f == 4:
+            for i in range(stride):
+                a = cur[i - ch] if i >= ch else 0
+                b = prev[i]
+                c = prev[i - ch] if i >= ch else 0
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (cur[i] + pr) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, ch)
+
+
+def main():
+    img = read_png(SRC)
+    h, w, _ = img.shape
+    assert (w, h) == (1280, 702)
+    pts = []
+    # top band of the image (pure sky) on a coarse grid, and the left edge above the horizon
+    for y_top in (2, 40, 80, 120, 160):
+        for x in (5, 160, 400, 640, 880, 1120, 1274):
+            pts.append((x, y_top))
+    for y_top in (220, 280, 340, 380):
+        pts.append((8, y_top))
+        pts.append((1270, y_top))
+    rows = []
+    for x, y_top in pts:
+        r, g, b = (int(v) for v in img[y_top, x, :3])
+        rows.append({"x": x, "y_from_bottom": h - 1 - y_top, "rgb": [r, g, b]})
+    out = {"source": "images/14.png of the reference (1280x702)", "width": w, "height": h, "pixels": rows}
+    json.dump(out, open(os.path.join(HERE, "reference_sky_pixels.json"), "w"), indent=1)
+    print("wrote", len(rows), "sky pixels")
+
+
+if __name__ == "__main__":
+    main()

@@ -460,3 +460,22 @@ def test_center_hit_f64_matches_fp32(ora, lib):
     h = ora.OraHit()
     assert L.ora_hit_world(dev, n, f3(tuple(p.camera_origin)), f3(d), C.byref(h)) == 1
     assert h.index == hit.uuid and abs(h.t - hit.t) < 1e-5
+
+
+# ------------------------------------------------- 9. the reference's own screenshot (sky pixels)
+def test_sky_pixels_of_the_reference_screenshot(ora):
+    """43 sky pixels of the reference's published render of State::default (images/14.png,
+    tests/golden/make_sky_fixture.py).  Sky pixels have no Monte-Carlo noise, so they pin the
+    camera derivation, the pixel -> v_position -> st mapping and its bottom-up row order,
+    background() and the sqrt gamma against the reference's REAL output, to +-1.5/255."""
+    with open(os.path.join(GOLDEN, "reference_sky_pixels.json")) as f:
+        fx = json.load(f)
+    sc = scenes.default_scene(fx["width"], fx["height"], spp=8, max_depth=8)
+    worst = 0.0
+    for px in fx["pixels"]:
+        x, y = px["x"], px["y_from_bottom"]
+        acc, seg = ora.render(sc.spheres, sc.params, 1, window=(x, x + 1, y, y + 1), nthreads=1)
+        assert seg == 8  # every sample escapes straight to the sky
+        got = np.sqrt(acc[y, x, :3] / 8.0) * 255.0
+        worst = max(worst, float(np.abs(got - np.array(px["rgb"], dtype=np.float64)).max()))
+    assert worst <= 1.5, worst
