@@ -225,6 +225,8 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   // allow the trace kernel to use the CU's whole 160 KiB LDS for big sphere lists
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_scalar),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -486,10 +488,13 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   }
   const bool in_lds = path == PT_GEOM_LDS;
   c->geom_last = path;
-  size_t lds = in_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
+  // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
+  const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
+  size_t lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
   uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
   const void* kfn = in_lds ? reinterpret_cast<const void*>(pt_trace_kernel)
-                           : reinterpret_cast<const void*>(pt_trace_kernel_scalar);
+                           : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
+                                       : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
@@ -540,7 +545,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   }
   if (ev) PT_HIP(c, hipEventRecord(ev->first, c->stream));
   if (in_lds) hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
-  else hipLaunchKernelGGL(pt_trace_kernel_scalar, dim3(grid), dim3(block), 0, c->stream, A);
+  else if (have_lds) hipLaunchKernelGGL(pt_trace_kernel_scalar, dim3(grid), dim3(block), lds, c->stream, A);
+  else hipLaunchKernelGGL(pt_trace_kernel_scalar_nolds, dim3(grid), dim3(block), 0, c->stream, A);
   PT_HIP(c, hipGetLastError());
   if (ev) PT_HIP(c, hipEventRecord(ev->second, c->stream));
   if (trial >= 0) {

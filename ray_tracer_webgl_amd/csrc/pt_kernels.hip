@@ -156,36 +156,46 @@ using namespace ptd;
 // --------------------------------------------------------------------------------------------
 // The path-tracing kernel body.
 // --------------------------------------------------------------------------------------------
-// GEOM_IN_LDS = true : the list is staged into LDS once per workgroup (every BASELINE config).
-// GEOM_IN_LDS = false: the list is walked straight from the padded global copy with
-//                      wave-uniform SCALAR loads (constant address space -> s_load_dwordx4 via
-//                      the scalar cache / L2); sphere data reaches the VALU as SGPR operands,
-//                      no LDS traffic, 12 fewer VGPRs.  Same arithmetic, bit-identical images.
-//                      Faster on dense mid-size scenes (config 2: -11 %), slower once the list
-//                      outgrows the scalar cache; PT_GEOM_AUTO measures both per scene.  Also
-//                      the only path for lists beyond the 160 KiB LDS (n > 10 232).
-template <bool GEOM_IN_LDS>
+// SCAN_LDS   : the scan (PHASE 1) walks the LDS copy with wave-uniform ds_read_b128 broadcasts.
+// !SCAN_LDS  : the scan walks the padded global copy with wave-uniform SCALAR loads (constant
+//              address space -> s_load_dwordx16 per four spheres via the scalar cache / L2);
+//              sphere data reaches the VALU as SGPR operands, no LDS traffic in the scan, 12
+//              fewer VGPRs.  Same arithmetic, bit-identical images.  Faster on dense mid-size
+//              scenes (config 2: -11 %), slower once the list outgrows the scalar cache;
+//              PT_GEOM_AUTO measures both per scene.
+// HAVE_LDS   : an LDS copy of the list exists (n <= 10 232) and serves every PER-LANE indexed
+//              read (exact phase, tail mode, shading) whichever way the scan reads; without it
+//              (lists beyond the 160 KiB LDS) those gathers go to global memory.
+template <bool SCAN_LDS, bool HAVE_LDS>
 __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
+  static_assert(HAVE_LDS || !SCAN_LDS, "an LDS scan needs the LDS copy");
   extern __shared__ float4 s_geom[];
   const float4* __restrict__ g_geom = reinterpret_cast<const float4*>(A.geom);
 
-  // ---- stage the (already padded, {cx,cy,cz,r*r}) geometry once per workgroup ----------------
-  if constexpr (GEOM_IN_LDS) {
+  // ---- copy the (already padded, {cx,cy,cz,r*r}) geometry into LDS once per workgroup --------
+  if constexpr (HAVE_LDS) {
     const uint32_t n_padded = PT_LDS_ENTRIES(A.n_spheres);
     for (uint32_t i = threadIdx.x; i < n_padded; i += blockDim.x) s_geom[i] = g_geom[i];
     __syncthreads();
   }
-  // constant address space: a wave-uniform index becomes one scalar load (s_load_dwordx4) whose
-  // result feeds the VALU as SGPR operands; a per-lane index (exact phase) becomes a vector load
   typedef float f4v __attribute__((ext_vector_type(4)));
   typedef const f4v __attribute__((address_space(4))) const_f4v;
   const_f4v* c_geom = (const_f4v*)A.geom;
-  auto geom_at = [&](uint32_t i) -> float4 {
-    if constexpr (GEOM_IN_LDS) {
+  // wave-uniform index (the scan)
+  auto geom_scan = [&](uint32_t i) -> float4 {
+    if constexpr (SCAN_LDS) {
       return s_geom[i];
     } else {
       const f4v v = c_geom[i];
       return make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  // per-lane index (exact phase, tail mode, shading)
+  auto geom_at = [&](uint32_t i) -> float4 {
+    if constexpr (HAVE_LDS) {
+      return s_geom[i];
+    } else {
+      return g_geom[i];
     }
   };
 
@@ -466,14 +476,14 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
     {
       const uint32_t n_groups8 = (n_spheres + 7u) & ~7u;
-      float4 a0 = geom_at(0), a1 = geom_at(1), a2 = geom_at(2), a3 = geom_at(3);
+      float4 a0 = geom_scan(0), a1 = geom_scan(1), a2 = geom_scan(2), a3 = geom_scan(3);
       for (uint32_t i = 0; i < n_groups8; i += 8) {
-        float4 b0 = geom_at(i + 4), b1 = geom_at(i + 5), b2 = geom_at(i + 6), b3 = geom_at(i + 7);
+        float4 b0 = geom_scan(i + 4), b1 = geom_scan(i + 5), b2 = geom_scan(i + 6), b3 = geom_scan(i + 7);
         PT_GROUP(a0, a1, a2, a3, i)
-        a0 = geom_at(i + 8); // the list is padded by one extra group, so this stays in bounds
-        a1 = geom_at(i + 9);
-        a2 = geom_at(i + 10);
-        a3 = geom_at(i + 11);
+        a0 = geom_scan(i + 8); // the list is padded by one extra group, so this stays in bounds
+        a1 = geom_scan(i + 9);
+        a2 = geom_scan(i + 10);
+        a3 = geom_scan(i + 11);
         PT_GROUP(b0, b1, b2, b3, i + 4u)
       }
     }
@@ -521,7 +531,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         tl_p3_entries++; tl_p3_spheres += n_spheres - start; tl_ovf_lanes += __popcll(lit_mask);
 #endif
         for (uint32_t i = start; i < n_spheres; i++) {
-          const float4 g = geom_at(i);
+          const float4 g = geom_scan(i);
           PT_TEST(g, half_b, c, disc)
           (void)c;
           if (lit && i >= lit_from && !(disc < 0.0f)) { // :153 (NaN falls through)
@@ -665,12 +675,17 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 // blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
 // workgroup fits per CU); dynamic LDS = PT_LDS_ENTRIES(n_spheres) * 16 bytes.
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKernelArgs A) {
-  pt_trace_body<true>(A);
+  pt_trace_body<true, true>(A);
 }
 
-// the scalar-load walk (PT_GEOM_SCALAR): no dynamic LDS, 256-thread workgroups
+// the scalar-load walk (PT_GEOM_SCALAR) with the LDS copy kept for the per-lane gathers
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar(const PtKernelArgs A) {
-  pt_trace_body<false>(A);
+  pt_trace_body<false, true>(A);
+}
+
+// lists beyond the LDS (10 232 < n <= 65 528): scalar-load walk, gathers from global memory
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(const PtKernelArgs A) {
+  pt_trace_body<false, false>(A);
 }
 
 // --------------------------------------------------------------------------------------------
