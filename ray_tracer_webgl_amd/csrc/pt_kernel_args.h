@@ -36,7 +36,7 @@ struct PtKernelArgs {
   float* slab;                // n_passes * local_rows * width * float4 (rgb sum, spp)
   unsigned long long* counters;  // [0] work-queue head, [1] segments, [2] samples
   const uint32_t* tile_order;    // n_tiles: queue position -> tile (heaviest tiles first)
-  uint32_t* tile_cost;           // n_tiles: segments traced per tile (feeds the next launch's order)
+  uint32_t* tile_cost;           // n_tiles: longest item (segments) per tile, feeds the next launch's order
   unsigned long long* timeline;  // dev builds (-DPT_TIMELINE) only: 8 u64 per wave; NULL otherwise
 };
 

@@ -10,6 +10,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 sc = scenes.config2(1920, 1080, 64, 16, 50)
 pt = PathTracer(1920, 1080)
 pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(16)
+if os.environ.get('PT_GEOM'):
+    pt.set_geometry_path(int(os.environ['PT_GEOM']))
 pt.render_passes(n); pt.synchronize(); pt.reset()
 pt.render_passes(n); pt.synchronize()
 lib = pt.lib
