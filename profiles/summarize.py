@@ -62,7 +62,7 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
     out["pt_trace_kernel_hbm_bytes_per_launch"] = int(traffic)
     print("  HBM traffic per launch (WRITE_SIZE + 2*FETCH_SIZE): %.4g bytes" % traffic)
     json.dump({"pt_trace_kernel_hbm_bytes_per_launch": int(traffic), "kernel": out.get("pmc_kernel"),
-               "workload": "bench.py --steps 16 --warmup 32 (config 2, 16 passes per launch; 1 LDS + 2 scalar dispatches)",
+               "workload": "bench.py --steps 16 --warmup 16 (config 2, 16 passes per launch; pt_tune: 2 LDS + 1 scalar dispatches, then 2 scalar)",
                "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]},
               open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
