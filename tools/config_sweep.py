@@ -16,14 +16,16 @@ for name, sc, n in cases:
     pt.set_spheres(sc.spheres)
     pt.set_params(sc.params)
     pt.reserve_passes(n)
-    pt.render_passes(1); pt.synchronize(); pt.reset()
+    pt.tune(n)
     t0 = time.perf_counter()
     pt.render_passes(n)
     pt.synchronize()
     dt = time.perf_counter() - t0
     st = pt.stats()
     tests = st.segments * len(sc.spheres)
-    print("%-8s %5d spheres %dx%d %d passes x %d spp: %.1f ms, %.1f Mray/s, %.2f Ttests/s, %.1f TFLOP/s(20/test)" % (
-        name, len(sc.spheres), sc.params.width, sc.params.height, n, sc.params.samples_per_pixel, dt * 1e3,
+    from ray_tracer_webgl_amd import abi
+    print("%-8s %5d spheres %dx%d %d passes x %d spp [%s]: %.1f ms, %.1f Mray/s, %.2f Ttests/s, %.1f TFLOP/s(20/test)" % (
+        name, len(sc.spheres), sc.params.width, sc.params.height, n, sc.params.samples_per_pixel,
+        abi.GEOM_NAMES.get(st.geometry_path), dt * 1e3,
         st.segments / dt / 1e6, tests / dt / 1e12, 20 * tests / dt / 1e12), flush=True)
     pt.close()
