@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the RCCL code path even with one rank (rehearsal of the collectives on a one-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,13 +74,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    use_dist = world > 1
+    use_dist = world > 1 or args.force_dist
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if use_dist:
         import torch.distributed as dist
 
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
