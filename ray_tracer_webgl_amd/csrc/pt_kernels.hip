@@ -475,9 +475,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   }
 
     {
-      const uint32_t n_groups8 = (n_spheres + 7u) & ~7u;
+      // pairs of groups (two ping-pong register sets), then at most one trailing group of four
+      const uint32_t n_groups4 = (n_spheres + 3u) & ~3u;
       float4 a0 = geom_scan(0), a1 = geom_scan(1), a2 = geom_scan(2), a3 = geom_scan(3);
-      for (uint32_t i = 0; i < n_groups8; i += 8) {
+      uint32_t i = 0;
+      for (; i + 8u <= n_groups4; i += 8) {
         float4 b0 = geom_scan(i + 4), b1 = geom_scan(i + 5), b2 = geom_scan(i + 6), b3 = geom_scan(i + 7);
         PT_GROUP(a0, a1, a2, a3, i)
         a0 = geom_scan(i + 8); // the list is padded by one extra group, so this stays in bounds
@@ -486,6 +488,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         a3 = geom_scan(i + 11);
         PT_GROUP(b0, b1, b2, b3, i + 4u)
       }
+      if (i < n_groups4) PT_GROUP(a0, a1, a2, a3, i)
     }
 #undef PT_GROUP
 
