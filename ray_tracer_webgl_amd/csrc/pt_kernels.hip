@@ -207,6 +207,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   // ---- per-lane path state ---------------------------------------------------------------------
   bool alive = false;     // lane holds a live ray
   bool exhausted = false; // queue returned "no more items" to this lane
+  bool new_path = false;  // lane must generate its next camera ray before the next scan
   uint32_t slab_index = 0;
   uint32_t item_tile = 0xffffffffu, item_segs = 0; // cost feedback for the next launch's tile order
   int sample = 0, depth = 0;
@@ -306,12 +307,18 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             item_segs = 0;
             sum = mk(0.f, 0.f, 0.f);
             sample = 0;
-            start_sample();
+            new_path = true;
             alive = true;
           }
           // an item that falls outside the image (edge tile) is simply dropped
         }
       }
+    }
+    // one copy of the camera-ray code per step serves both kinds of lanes: those that just
+    // pulled an item and those whose previous path ended in the last step
+    if (alive && new_path) {
+      start_sample();
+      new_path = false;
     }
     unsigned long long live = __ballot(alive);
     if (live == 0ull) break; // every lane is exhausted: the queue is dry
@@ -656,7 +663,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           if (item_tile != 0xffffffffu) atomicMax(&A.tile_cost[item_tile], item_segs);
           alive = false;
         } else {
-          start_sample();
+          new_path = true;
         }
       }
     }
