@@ -19,7 +19,9 @@
  * ora_center_hit_f64, (d) the committed fixtures under tests/golden/, which this oracle
  * itself generated (tests/golden/make_golden.py), and (e) for the deterministic part of the path
  * (camera, pixel mapping, background, gamma) 43 sky pixels of the reference's own published
- * screenshot of State::default, matched to +-1.5/255 (tests/golden/reference_sky_pixels.json).
+ * screenshot of State::default, matched to +-1.5/255 (tests/golden/reference_sky_pixels.json),
+ * and that screenshot's sky / not-sky silhouettes, matched on every pixel outside a 2-pixel
+ * antialiasing band (tests/golden/reference_sky_mask.npz) -> scene geometry and camera.
  * The Monte-Carlo part (RNG use, scatter, accumulation) remains unpinned.
  *
  * ARITHMETIC CONTRACT ("PT-SPEC").  GLSL leaves operation order, fusion and
@@ -516,6 +518,25 @@ ORA_API void ora_camera_ray(const PtParams* p, float s, float t, float* seed, fl
   ray_t r = get_ray_from_camera(p, s, t, seed);
   origin[0] = r.origin.x; origin[1] = r.origin.y; origin[2] = r.origin.z;
   dir[0] = r.direction.x; dir[1] = r.direction.y; dir[2] = r.direction.z;
+}
+
+
+/* First-hit map through pixel CENTRES (no jitter, no lens): uuid of the nearest sphere or -1.
+ * Used to compare silhouettes with the reference's screenshot (tests/test_oracle_kat.py). */
+ORA_API void ora_first_hit_map(const PtSphere* spheres, uint32_t n, const PtParams* p, int32_t* out) {
+  v3 o = V(p->camera_origin[0], p->camera_origin[1], p->camera_origin[2]);
+  for (uint32_t y = 0; y < p->height; y++)
+    for (uint32_t x = 0; x < p->width; x++) {
+      float vx = v_position_of(x, p->width), vy = v_position_of(y, p->height);
+      float s = (vx + 1.0f) * 0.5f, t = (vy + 1.0f) * 0.5f;
+      ray_t r;
+      r.origin = o;
+      r.direction = vsub(V(fmaf(t, p->vertical[0], fmaf(s, p->horizontal[0], p->lower_left_corner[0])),
+                           fmaf(t, p->vertical[1], fmaf(s, p->horizontal[1], p->lower_left_corner[1])),
+                           fmaf(t, p->vertical[2], fmaf(s, p->horizontal[2], p->lower_left_corner[2]))), o);
+      hit_record_t h;
+      out[(size_t)y * p->width + x] = hit_world(spheres, n, &r, ORA_MIN_T, ORA_MAX_T, &h) ? h.uuid : -1;
+    }
 }
 
 /* ============================ frame drivers ============================================== */

@@ -85,6 +85,33 @@ def main():
     json.dump(out, open(os.path.join(HERE, "reference_sky_pixels.json"), "w"), indent=1)
     print("wrote", len(rows), "sky pixels")
 
+    # Silhouette mask: which pixels of the screenshot show unobstructed sky.  A pixel counts as sky
+    # when it is within 2.5/255 of the analytic sky colour of the camera ray through its centre
+    # (State::default camera, src/state.rs:98-125, evaluated here in numpy doubles, independently of
+    # the oracle).  Row 0 of the stored mask is the BOTTOM image row.
+    import math
+    origin = np.array([0.0, 0.0, 1.0])
+    yaw = -90.0 * math.pi / 180.0
+    front = np.array([math.cos(yaw), 0.0, math.sin(yaw)])
+    wv = origin - (origin + front)
+    wv /= np.linalg.norm(wv)
+    u = np.cross([0.0, 1.0, 0.0], wv)
+    u /= np.linalg.norm(u)
+    v = np.cross(wv, u)
+    vh = 2.0 * math.tan(math.pi / 6.0)
+    vw = vh * (w / h)
+    horiz, vert = 0.75 * vw * u, 0.75 * vh * v
+    llc = origin - horiz / 2 - vert / 2 - 0.75 * wv
+    S = ((2 * np.arange(w) + 1) / w - 1 + 1) * 0.5
+    T = ((2 * np.arange(h) + 1) / h - 1 + 1) * 0.5
+    d = llc[None, None, :] + S[None, :, None] * horiz[None, None, :] + T[:, None, None] * vert[None, None, :] - origin
+    t = 0.5 * (d[..., 1] / np.linalg.norm(d, axis=-1) + 1.0)
+    sky = np.sqrt(np.stack([(1 - t) + 0.5 * t, (1 - t) + 0.7 * t, (1 - t) + 1.0 * t], -1)) * 255.0
+    bottom_up = img[::-1, :, :3].astype(np.float64)
+    mask = np.abs(bottom_up - sky).max(axis=-1) <= 2.5
+    np.savez_compressed(os.path.join(HERE, "reference_sky_mask.npz"), packed=np.packbits(mask), shape=np.array(mask.shape))
+    print("wrote sky mask: %.2f %% of the pixels are sky" % (100.0 * mask.mean()))
+
 
 if __name__ == "__main__":
     main()

@@ -479,3 +479,37 @@ def test_sky_pixels_of_the_reference_screenshot(ora):
         got = np.sqrt(acc[y, x, :3] / 8.0) * 255.0
         worst = max(worst, float(np.abs(got - np.array(px["rgb"], dtype=np.float64)).max()))
     assert worst <= 1.5, worst
+
+
+def test_silhouettes_of_the_reference_screenshot(ora):
+    """Where the reference's screenshot of State::default shows unobstructed sky and where it does
+    not (tests/golden/reference_sky_mask.npz, from images/14.png) against the oracle's first-hit
+    map through pixel centres: outside a 2-pixel band around the silhouettes (antialiasing) and
+    outside the glass / metal spheres (whose interiors may legitimately look like sky) the two
+    agree on EVERY one of ~700 000 pixels.  This pins the sphere centres and radii of
+    src/state.rs:148-257 as uploaded, the ground horizon and the camera to the reference's output."""
+    z = np.load(os.path.join(GOLDEN, "reference_sky_mask.npz"))
+    h, w = (int(v) for v in z["shape"])
+    ref_is_sky = np.unpackbits(z["packed"])[: h * w].reshape(h, w).astype(bool)
+    sc = scenes.default_scene(w, h, spp=1, max_depth=8)
+    ptr, n, keep = abi.spheres_as_ctypes(sc.spheres)
+    first = np.zeros((h, w), np.int32)
+    L = ora.load()
+    L.ora_first_hit_map.argtypes = [C.POINTER(abi.PtSphere), C.c_uint32, C.POINTER(abi.PtParams), C.c_void_p]
+    L.ora_first_hit_map(ptr, n, C.byref(sc.params), first.ctypes.data_as(C.c_void_p))
+    mine_is_sky = first < 0
+    assert set(np.unique(first).tolist()) == {-1, 0, 1, 2, 3, 4, 5, 7}  # "behind" (6) and the moon's moon (8) are not in view
+
+    def dilate(m, it=2):
+        for _ in range(it):
+            g = m.copy()
+            g[1:, :] |= m[:-1, :]; g[:-1, :] |= m[1:, :]; g[:, 1:] |= m[:, :-1]; g[:, :-1] |= m[:, 1:]
+            g[1:, 1:] |= m[:-1, :-1]; g[:-1, :-1] |= m[1:, 1:]; g[1:, :-1] |= m[:-1, 1:]; g[:-1, 1:] |= m[1:, :-1]
+            m = g
+        return m
+
+    edge = dilate(mine_is_sky) & dilate(~mine_is_sky)
+    specular = np.isin(first, [2, 3, 4, 5])  # metal, glass, the two negative-radius metal spheres
+    consider = ~edge & ~specular
+    assert consider.sum() > 650000
+    assert int(((ref_is_sky != mine_is_sky) & consider).sum()) == 0
