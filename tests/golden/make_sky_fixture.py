@@ -112,6 +112,56 @@ def main():
     np.savez_compressed(os.path.join(HERE, "reference_sky_mask.npz"), packed=np.packbits(mask), shape=np.array(mask.shape))
     print("wrote sky mask: %.2f %% of the pixels are sky" % (100.0 * mask.mean()))
 
+    # Mirror pixels: interior pixels of the metal spheres (fuzz 0) whose reflection goes straight to
+    # the sky.  Their colour is albedo * sky(reflected direction), free of Monte-Carlo noise, so
+    # they pin hit point, normal orientation (also for the NEGATIVE radii, src/state.rs:200,213)
+    # and reflect() against the reference's output.  Pixels are chosen with the oracle (5x5
+    # neighbourhood on the same sphere, every neighbour a 2-segment hit->sky path); only their
+    # coordinates and the screenshot's RGB are stored.
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle
+    from ray_tracer_webgl_amd import abi, scenes
+
+    L = oracle.load()
+    sc = scenes.default_scene(w, h, spp=1, max_depth=8)
+    ptr, n, keep = abi.spheres_as_ctypes(sc.spheres)
+    first = np.zeros((h, w), np.int32)
+    L.ora_first_hit_map.argtypes = [C.POINTER(abi.PtSphere), C.c_uint32, C.POINTER(abi.PtParams), C.c_void_p]
+    L.ora_first_hit_map(ptr, n, C.byref(sc.params), first.ctypes.data_as(C.c_void_p))
+
+    def centre_path(x, y):
+        vx, vy = np.float32((2 * x + 1) / np.float32(w)) - np.float32(1), np.float32((2 * y + 1) / np.float32(h)) - np.float32(1)
+        s_, t_ = np.float32((vx + np.float32(1)) * np.float32(0.5)), np.float32((vy + np.float32(1)) * np.float32(0.5))
+        seed = C.c_float(0.0)
+        o, dd = (C.c_float * 3)(), (C.c_float * 3)()
+        L.ora_camera_ray(C.byref(sc.params), float(s_), float(t_), C.byref(seed), o, dd)
+        col, seg = (C.c_float * 3)(), C.c_uint64()
+        L.ora_ray_color(ptr, n, C.byref(sc.params), o, dd, C.byref(seed), col, C.byref(seg))
+        return seg.value, np.sqrt(np.array(col[:], dtype=np.float64)) * 255.0
+
+    rng = np.random.default_rng(14)
+    mirror = []
+    for sid, want in ((2, 120), (4, 25), (5, 25)):
+        ys, xs = np.where(first == sid)
+        order = rng.permutation(len(ys))
+        got = 0
+        for k in order:
+            y, x = int(ys[k]), int(xs[k])
+            if y < 2 or x < 2 or y >= h - 2 or x >= w - 2 or not (first[y - 2:y + 3, x - 2:x + 3] == sid).all():
+                continue
+            if any(centre_path(x + dx, y + dy)[0] != 2 for dx in (-2, 0, 2) for dy in (-2, 0, 2)):
+                continue
+            r, g, b = (int(v) for v in img[h - 1 - y, x, :3])
+            mirror.append({"x": x, "y_from_bottom": y, "sphere": sid, "rgb": [r, g, b]})
+            got += 1
+            if got == want:
+                break
+    json.dump({"source": "images/14.png of the reference (1280x702)", "width": w, "height": h, "pixels": mirror},
+              open(os.path.join(HERE, "reference_mirror_pixels.json"), "w"), indent=1)
+    print("wrote", len(mirror), "mirror pixels")
+
 
 if __name__ == "__main__":
     main()

@@ -513,3 +513,33 @@ def test_silhouettes_of_the_reference_screenshot(ora):
     consider = ~edge & ~specular
     assert consider.sum() > 650000
     assert int(((ref_is_sky != mine_is_sky) & consider).sum()) == 0
+
+
+def test_mirror_pixels_of_the_reference_screenshot(ora):
+    """Interior pixels of the three fuzz-0 metal spheres (two of them with NEGATIVE radius) whose
+    reflection goes straight to the sky, from the reference's screenshot
+    (tests/golden/reference_mirror_pixels.json): noise-free, so they pin the hit point, the
+    outward-normal orientation rule, reflect() and the metal branch of scatter() against the
+    reference's real output, to +-3/255."""
+    with open(os.path.join(GOLDEN, "reference_mirror_pixels.json")) as f:
+        fx = json.load(f)
+    L = ora.load()
+    w, h = fx["width"], fx["height"]
+    sc = scenes.default_scene(w, h, spp=1, max_depth=8)
+    ptr, n, keep = abi.spheres_as_ctypes(sc.spheres)
+    assert len(fx["pixels"]) >= 100 and {p["sphere"] for p in fx["pixels"]} == {2, 4, 5}
+    worst = 0.0
+    for px in fx["pixels"]:
+        x, y = px["x"], px["y_from_bottom"]
+        vx = np.float32((2 * x + 1) / np.float32(w)) - np.float32(1)
+        vy = np.float32((2 * y + 1) / np.float32(h)) - np.float32(1)
+        s_, t_ = np.float32((vx + np.float32(1)) * np.float32(0.5)), np.float32((vy + np.float32(1)) * np.float32(0.5))
+        seed = C.c_float(0.0)
+        o, d = (C.c_float * 3)(), (C.c_float * 3)()
+        L.ora_camera_ray(C.byref(sc.params), float(s_), float(t_), C.byref(seed), o, d)
+        col, seg = (C.c_float * 3)(), C.c_uint64()
+        L.ora_ray_color(ptr, n, C.byref(sc.params), o, d, C.byref(seed), col, C.byref(seg))
+        assert seg.value == 2  # mirror, then sky
+        got = np.sqrt(np.array(col[:], dtype=np.float64)) * 255.0
+        worst = max(worst, float(np.abs(got - np.array(px["rgb"], dtype=np.float64)).max()))
+    assert worst <= 3.0, worst
