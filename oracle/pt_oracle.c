@@ -22,7 +22,7 @@
  * screenshot of State::default, matched to +-1.5/255 (tests/golden/reference_sky_pixels.json),
  * and that screenshot's sky / not-sky silhouettes, matched on every pixel outside a 2-pixel
  * antialiasing band (tests/golden/reference_sky_mask.npz) -> scene geometry and camera, and 170
- * mirror pixels of its fuzz-0 metal spheres (+-3/255, reference_mirror_pixels.json) -> hit point,
+ * mirror pixels of its fuzz-0 metal spheres (+-2/255, reference_mirror_pixels.json) -> hit point,
  * normal orientation for either sign of the radius, reflect(), metal scatter.
  * The Monte-Carlo part (RNG use, scatter, accumulation) remains unpinned.
  *

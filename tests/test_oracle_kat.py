@@ -520,7 +520,7 @@ def test_mirror_pixels_of_the_reference_screenshot(ora):
     reflection goes straight to the sky, from the reference's screenshot
     (tests/golden/reference_mirror_pixels.json): noise-free, so they pin the hit point, the
     outward-normal orientation rule, reflect() and the metal branch of scatter() against the
-    reference's real output, to +-3/255."""
+    reference's real output, to +-2/255."""
     with open(os.path.join(GOLDEN, "reference_mirror_pixels.json")) as f:
         fx = json.load(f)
     L = ora.load()
@@ -542,4 +542,4 @@ def test_mirror_pixels_of_the_reference_screenshot(ora):
         assert seg.value == 2  # mirror, then sky
         got = np.sqrt(np.array(col[:], dtype=np.float64)) * 255.0
         worst = max(worst, float(np.abs(got - np.array(px["rgb"], dtype=np.float64)).max()))
-    assert worst <= 3.0, worst
+    assert worst <= 2.0, worst
