@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 /* ---- error codes (returned by every int function; 0 = success) ------------------------------ */
 enum {
@@ -43,18 +43,25 @@ enum {
   PT_EMISSIVE = 3, /* build extension (BASELINE config 4): emits `albedo`, absorbs the path     */
 };
 
-/* ---- how the intersection loop reads the sphere list (pt_set_option PT_OPT_GEOMETRY_PATH) ------
- * Both walk the same padded list with the same arithmetic and give bit-identical images.
- *   LDS    the list is staged into LDS once per workgroup, ds_read_b128 broadcasts (n <= 10 232)
- *   SCALAR wave-uniform scalar loads (s_load_dwordx4) through the scalar cache / L2; sphere
- *          data reaches the VALU as SGPR operands (any n up to 65 528)
- *   AUTO   (default) after pt_set_spheres the first launch runs cold (LDS, unmeasured), the
- *          second and third measure one path each, and the faster one (time per camera
- *          sample) is used from then on                                                     */
+/* ---- how the intersection loop looks at the sphere list (pt_set_option PT_OPT_GEOMETRY_PATH) --
+ * All of them run the same fp32 arithmetic on every sphere that can possibly be hit and give
+ * bit-identical images.
+ *   LDS    the whole list, staged into LDS once per workgroup, ds_read_b128 broadcasts
+ *          (n <= 10 232)
+ *   SCALAR the whole list through wave-uniform scalar loads (s_load_dwordx16) via the scalar
+ *          cache / L2; sphere data reaches the VALU as SGPR operands (any n up to 65 528)
+ *   BVH    a bounding-box hierarchy built by pt_set_spheres decides which spheres a ray looks
+ *          at: boxes are inflated by a per-ray margin that covers the rounding of the literal
+ *          test, so only spheres that cannot pass it are skipped (regular scenes of >= 16
+ *          spheres; a scene without a hierarchy falls back to SCALAR)
+ *   AUTO   (default) after pt_set_spheres the first launch runs cold (unmeasured), the next
+ *          ones measure one usable path each, and the fastest (time per camera sample) is
+ *          used from then on                                                                 */
 enum {
   PT_GEOM_AUTO = 0,
   PT_GEOM_LDS = 1,
   PT_GEOM_SCALAR = 2,
+  PT_GEOM_BVH = 3,
 };
 enum {
   PT_OPT_GEOMETRY_PATH = 1,
@@ -150,8 +157,12 @@ typedef struct PtStats {
   uint32_t total_spp;       /* samples per pixel accumulated                                    */
   uint32_t n_spheres;
   uint32_t local_rows;      /* rows held by this context (row partition)                        */
-  uint32_t geometry_path;   /* PT_GEOM_LDS / PT_GEOM_SCALAR used by the most recent launch          */
-  uint32_t geometry_tuned;  /* 1 once PT_GEOM_AUTO has measured both paths for this scene           */
+  uint32_t geometry_path;   /* PT_GEOM_LDS / _SCALAR / _BVH used by the most recent launch          */
+  uint32_t geometry_tuned;  /* 1 once PT_GEOM_AUTO has measured the usable paths for this scene     */
+  uint32_t bvh_nodes;       /* hierarchy of the current scene: nodes (0 = none), slots (4 per leaf   */
+  uint32_t bvh_slots;       /* + the spheres tested for every ray), how many of those, depth        */
+  uint32_t bvh_outliers;
+  uint32_t bvh_depth;
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -208,10 +219,20 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 int pt_get_stats(pt_ctx* ctx, PtStats* out);
 int pt_set_option(pt_ctx* ctx, int key, int value);
-/* Settles PT_GEOM_AUTO now instead of lazily: renders n_passes passes three times with the
- * current scene and uniforms (cold, LDS, scalar), keeps the faster path, then clears the
+/* Settles PT_GEOM_AUTO now instead of lazily: renders n_passes passes with the current scene
+ * and uniforms once cold and once per usable path, keeps the fastest path, then clears the
  * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes. */
 int pt_tune(pt_ctx* ctx, uint32_t n_passes);
+/* The hierarchy pt_set_spheres builds for PT_GEOM_BVH, on the host (no device needed; tests
+ * check its invariants): nodes = 8 floats each {lo.xyz, bits(skip), hi.xyz, bits(first slot of
+ * the leaf | 0xffffffff)}, slots = 4 floats each {cx, cy, cz, r*r}, slot_index = original sphere
+ * index per slot (0xffffffff = padding), margin4 = {c0.xyz, s0}, counts5 = {n_nodes, n_slots,
+ * n_tree_slots, n_outliers, depth}.  Array pointers may be NULL (sizes only); capacities are in
+ * elements.  Returns PT_ERR_NOT_READY when the scene gets no hierarchy (fewer than 16 spheres,
+ * non-finite values), PT_ERR_CAPACITY when an array is too small. */
+int pt_build_bvh(const PtSphere* spheres, uint32_t n, float* nodes, size_t node_floats, float* slots,
+                 size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
+                 uint32_t* counts5);
 const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
 int pt_abi_version(void);
 int pt_device_count(void);

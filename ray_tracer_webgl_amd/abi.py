@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-PT_ABI_VERSION = 1
+PT_ABI_VERSION = 2
 
 PT_OK = 0
 PT_ERR_INVALID = -1
@@ -28,9 +28,9 @@ PT_EMISSIVE = 3
 PT_BG_SKY = 0
 PT_BG_BLACK = 1
 
-PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR = 0, 1, 2
+PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH = 0, 1, 2, 3
 PT_OPT_GEOMETRY_PATH = 1
-GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar"}
+GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh"}
 
 f3 = C.c_float * 3
 d3 = C.c_double * 3
@@ -133,6 +133,10 @@ class PtStats(C.Structure):
         ("local_rows", C.c_uint32),
         ("geometry_path", C.c_uint32),
         ("geometry_tuned", C.c_uint32),
+        ("bvh_nodes", C.c_uint32),
+        ("bvh_slots", C.c_uint32),
+        ("bvh_outliers", C.c_uint32),
+        ("bvh_depth", C.c_uint32),
     ]
 
 

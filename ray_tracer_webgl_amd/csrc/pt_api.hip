@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/ptrace.h"
+#include "pt_bvh.hpp"
 #include "pt_kernel_args.h"
 
 #define PT_API extern "C" __attribute__((visibility("default")))
@@ -55,12 +56,22 @@ struct pt_ctx {
   size_t resolve_pixels = 0;
   // geometry path (include/ptrace.h PT_GEOM_*): policy, autotune state
   int geom_policy = PT_GEOM_AUTO;
-  int geom_tuned = 0;              // PT_GEOM_LDS / PT_GEOM_SCALAR once decided, 0 while measuring
+  int geom_tuned = 0;              // the path PT_GEOM_AUTO settled on, 0 while measuring
   int geom_last = PT_GEOM_LDS;     // path of the most recent launch
-  int trial_state = 0;             // 0: unmeasured first launch (cold), 1: next measures LDS,
-                                   // 2: next measures SCALAR, 3: both enqueued
-  hipEvent_t trial_ev[4] = {nullptr, nullptr, nullptr, nullptr}; // LDS begin/end, SCALAR begin/end
-  double trial_samples[2] = {0.0, 0.0};
+  int trial_paths[3] = {0, 0, 0};  // the paths this scene can use, in measuring order
+  int n_trials = 0;
+  int trial_state = 0;             // 0: unmeasured first launch (cold), k in 1..n_trials: the next
+                                   // launch measures trial_paths[k-1], n_trials+1: all enqueued
+  hipEvent_t trial_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // begin/end per trial
+  double trial_samples[3] = {0.0, 0.0, 0.0};
+  // culling hierarchy (PT_GEOM_BVH), rebuilt by pt_set_spheres; absent for tiny / irregular scenes
+  bool have_bvh = false;
+  float* d_bvh_nodes = nullptr;
+  float* d_bvh_slots = nullptr;
+  uint32_t* d_bvh_index = nullptr;
+  size_t bvh_node_cap = 0, bvh_slot_cap = 0;
+  uint32_t bvh_n_nodes = 0, bvh_n_slots = 0, bvh_n_tree_slots = 0, bvh_n_outliers = 0, bvh_depth = 0;
+  float bvh_c0[3] = {0, 0, 0}, bvh_s0 = 0;
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -157,17 +168,30 @@ int fold_events(pt_ctx* c) {
   return PT_OK;
 }
 
-// PT_GEOM_AUTO: once both trial launches have finished (non-blocking query), keep the path with
-// the lower time per camera sample.  Images do not depend on the choice.
+// PT_GEOM_AUTO: once every trial launch has finished (non-blocking query), keep the path with
+// the lowest time per camera sample.  Images do not depend on the choice.
 void try_finish_tuning(pt_ctx* c) {
-  if (c->geom_tuned || c->trial_state < 3) return;
-  if (hipEventQuery(c->trial_ev[1]) != hipSuccess || hipEventQuery(c->trial_ev[3]) != hipSuccess) return;
-  float ms_lds = 0.f, ms_sc = 0.f;
-  if (hipEventElapsedTime(&ms_lds, c->trial_ev[0], c->trial_ev[1]) != hipSuccess) return;
-  if (hipEventElapsedTime(&ms_sc, c->trial_ev[2], c->trial_ev[3]) != hipSuccess) return;
-  double a = (double)ms_lds / (c->trial_samples[0] > 0 ? c->trial_samples[0] : 1.0);
-  double b = (double)ms_sc / (c->trial_samples[1] > 0 ? c->trial_samples[1] : 1.0);
-  c->geom_tuned = b < a ? PT_GEOM_SCALAR : PT_GEOM_LDS;
+  if (c->geom_tuned || c->n_trials == 0 || c->trial_state <= c->n_trials) return;
+  for (int k = 0; k < c->n_trials; k++)
+    if (hipEventQuery(c->trial_ev[2 * k + 1]) != hipSuccess) return;
+  double best = 0.0;
+  int best_path = 0;
+  for (int k = 0; k < c->n_trials; k++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->trial_ev[2 * k], c->trial_ev[2 * k + 1]) != hipSuccess) return;
+    double per = (double)ms / (c->trial_samples[k] > 0 ? c->trial_samples[k] : 1.0);
+    if (best_path == 0 || per < best) { best = per; best_path = c->trial_paths[k]; }
+  }
+  c->geom_tuned = best_path;
+}
+
+// the geometry paths a scene can use, in measuring order (the first is also the default while
+// PT_GEOM_AUTO has not decided)
+void list_paths(pt_ctx* c) {
+  c->n_trials = 0;
+  if (c->n_spheres <= PT_MAX_SPHERES_LDS) c->trial_paths[c->n_trials++] = PT_GEOM_LDS;
+  c->trial_paths[c->n_trials++] = PT_GEOM_SCALAR;
+  if (c->have_bvh) c->trial_paths[c->n_trials++] = PT_GEOM_BVH;
 }
 
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
@@ -227,6 +251,8 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_scalar),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -241,6 +267,9 @@ PT_API int pt_destroy(pt_ctx* c) {
   for (hipEvent_t e : c->trial_ev) if (e) (void)hipEventDestroy(e);
   if (c->d_geom) (void)hipFree(c->d_geom);
   if (c->d_mat) (void)hipFree(c->d_mat);
+  if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
+  if (c->d_bvh_slots) (void)hipFree(c->d_bvh_slots);
+  if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
   if (c->own_accum) (void)hipFree(c->own_accum);
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_resolve) (void)hipFree(c->d_resolve);
@@ -287,6 +316,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     geom[4 * i + 0] = 1e15f; geom[4 * i + 1] = 1e15f; geom[4 * i + 2] = 1e15f; geom[4 * i + 3] = 0.0f;
   }
   std::vector<PtMatRec> mat(n);
+  std::vector<float> radii(n);
   bool regular = true;
   for (uint32_t i = 0; i < n; i++) {
     for (int k = 0; k < 3; k++) regular = regular && (std::fabs(s[i].center[k]) < 1e15f);
@@ -303,7 +333,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     mat[i].type = s[i].type;
     mat[i].radius = s[i].radius;
     mat[i].uuid = s[i].uuid;
+    radii[i] = s[i].radius;
   }
+  // the culling hierarchy of PT_GEOM_BVH (regular scenes of at least 16 spheres)
+  ptbvh::Bvh bvh;
+  const bool have_bvh = regular && ptbvh::build(geom.data(), radii.data(), n, &bvh);
   {
     // the stream may still be reading the previous scene
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -312,11 +346,38 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   if (n) {
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n * sizeof(PtMatRec), hipMemcpyHostToDevice));
   }
+  c->have_bvh = false;
+  if (have_bvh) {
+    if (bvh.nodes.size() > c->bvh_node_cap) {
+      if (c->d_bvh_nodes) PT_HIP(c, hipFree(c->d_bvh_nodes));
+      c->d_bvh_nodes = nullptr; c->bvh_node_cap = 0;
+      PT_HIP(c, hipMalloc(&c->d_bvh_nodes, bvh.nodes.size() * sizeof(float)));
+      c->bvh_node_cap = bvh.nodes.size();
+    }
+    if (bvh.slots.size() > c->bvh_slot_cap) {
+      if (c->d_bvh_slots) PT_HIP(c, hipFree(c->d_bvh_slots));
+      if (c->d_bvh_index) PT_HIP(c, hipFree(c->d_bvh_index));
+      c->d_bvh_slots = nullptr; c->d_bvh_index = nullptr; c->bvh_slot_cap = 0;
+      PT_HIP(c, hipMalloc(&c->d_bvh_slots, bvh.slots.size() * sizeof(float)));
+      PT_HIP(c, hipMalloc(&c->d_bvh_index, bvh.slot_index.size() * sizeof(uint32_t)));
+      c->bvh_slot_cap = bvh.slots.size();
+    }
+    PT_HIP(c, hipMemcpy(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_bvh_slots, bvh.slots.data(), bvh.slots.size() * sizeof(float), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_bvh_index, bvh.slot_index.data(), bvh.slot_index.size() * sizeof(uint32_t),
+                        hipMemcpyHostToDevice));
+    c->bvh_n_nodes = bvh.n_nodes; c->bvh_n_slots = bvh.n_slots; c->bvh_n_tree_slots = bvh.n_tree_slots;
+    c->bvh_n_outliers = bvh.n_outliers; c->bvh_depth = bvh.depth;
+    for (int k = 0; k < 3; k++) c->bvh_c0[k] = bvh.c0[k];
+    c->bvh_s0 = bvh.s0;
+    c->have_bvh = true;
+  }
   c->n_spheres = n;
   c->geom_tuned = 0;  // a new scene: PT_GEOM_AUTO measures again
   c->trial_state = 0;
   c->scene_regular = regular;
   c->have_spheres = true;
+  list_paths(c);
   return PT_OK;
 }
 
@@ -471,30 +532,55 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.tile_cost = c->d_tile_cost;
   A.timeline = nullptr;
 
-  // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
-  // per CU when the staged list takes most of the 160 KiB LDS
-  // which way the scan reads the list (bit-identical results either way)
+  // which way PHASE 1 looks at the sphere list (bit-identical results whichever way)
   int path = c->geom_policy;
-  int trial = -1; // 0 / 1 when this launch is an autotune measurement of LDS / SCALAR
-  if (c->n_spheres > PT_MAX_SPHERES_LDS) {
-    path = PT_GEOM_SCALAR;
-  } else if (path == PT_GEOM_AUTO) {
+  int trial = -1; // k when this launch is the autotune measurement of trial_paths[k]
+  if (path == PT_GEOM_AUTO) {
     try_finish_tuning(c);
     if (c->geom_tuned) path = c->geom_tuned;
-    else if (c->trial_state == 0) { path = PT_GEOM_LDS; c->trial_state = 1; } // cold launch: not measured
-    else if (c->trial_state == 1) { path = PT_GEOM_LDS; trial = 0; }
-    else if (c->trial_state == 2) { path = PT_GEOM_SCALAR; trial = 1; }
-    else path = PT_GEOM_LDS; // both trials still in flight
+    else if (c->trial_state == 0) { path = c->trial_paths[0]; c->trial_state = 1; } // cold launch: not measured
+    else if (c->trial_state <= c->n_trials) { trial = c->trial_state - 1; path = c->trial_paths[trial]; }
+    else path = c->trial_paths[0]; // trials still in flight
   }
-  const bool in_lds = path == PT_GEOM_LDS;
+  // a forced path the scene cannot use falls back to the nearest one it can
+  if (path == PT_GEOM_BVH && !c->have_bvh) path = PT_GEOM_SCALAR;
+  if (path == PT_GEOM_LDS && c->n_spheres > PT_MAX_SPHERES_LDS) path = PT_GEOM_SCALAR;
   c->geom_last = path;
-  // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
-  const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
-  size_t lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
+  // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
+  // per CU when the staged data takes most of the 160 KiB LDS
+  size_t lds = 0;
+  const void* kfn = nullptr;
+  A.coop_max_live = 16;
+  if (path == PT_GEOM_BVH) {
+    A.bvh_nodes = c->d_bvh_nodes;
+    A.bvh_slots = c->d_bvh_slots;
+    A.bvh_slot_index = c->d_bvh_index;
+    A.n_nodes = c->bvh_n_nodes;
+    A.n_tree_slots = c->bvh_n_tree_slots;
+    A.n_slots = c->bvh_n_slots;
+    for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
+    A.bvh_s0 = c->bvh_s0;
+    // tail mode costs ~n/64 rounds per live ray, the walk a roughly constant ~1500 issue slots
+    // per wave: the turn-around only pays for the last few rays of a wave
+    uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
+    uint32_t lim = 1500u / per_ray;
+    A.coop_max_live = lim > 16u ? 16u : lim;
+    size_t need = PT_BVH_LDS_BYTES(c->bvh_n_nodes, c->bvh_n_slots);
+    if (need <= (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16) {
+      lds = need;
+      kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh);
+    } else {
+      kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem);
+    }
+  } else {
+    // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
+    const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
+    lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
+    kfn = path == PT_GEOM_LDS ? reinterpret_cast<const void*>(pt_trace_kernel)
+                              : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
+                                          : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
+  }
   uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
-  const void* kfn = in_lds ? reinterpret_cast<const void*>(pt_trace_kernel)
-                           : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
-                                       : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
@@ -544,10 +630,10 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     PT_HIP(c, hipEventRecord(c->trial_ev[2 * trial], c->stream));
   }
   if (ev) PT_HIP(c, hipEventRecord(ev->first, c->stream));
-  if (in_lds) hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(block), lds, c->stream, A);
-  else if (have_lds) hipLaunchKernelGGL(pt_trace_kernel_scalar, dim3(grid), dim3(block), lds, c->stream, A);
-  else hipLaunchKernelGGL(pt_trace_kernel_scalar_nolds, dim3(grid), dim3(block), 0, c->stream, A);
-  PT_HIP(c, hipGetLastError());
+  {
+    void* kargs[] = {&A};
+    PT_HIP(c, hipLaunchKernel(kfn, dim3(grid), dim3(block), kargs, lds, c->stream));
+  }
   if (ev) PT_HIP(c, hipEventRecord(ev->second, c->stream));
   if (trial >= 0) {
     PT_HIP(c, hipEventRecord(c->trial_ev[2 * trial + 1], c->stream));
@@ -649,13 +735,19 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   out->local_rows = c->local_rows;
   out->geometry_path = (uint32_t)c->geom_last;
   out->geometry_tuned = c->geom_tuned ? 1u : 0u;
+  if (c->have_bvh) {
+    out->bvh_nodes = c->bvh_n_nodes;
+    out->bvh_slots = c->bvh_n_slots;
+    out->bvh_outliers = c->bvh_n_outliers;
+    out->bvh_depth = c->bvh_depth;
+  }
   return PT_OK;
 }
 
 PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   if (!c) return PT_ERR_INVALID;
   if (key == PT_OPT_GEOMETRY_PATH) {
-    if (value != PT_GEOM_AUTO && value != PT_GEOM_LDS && value != PT_GEOM_SCALAR)
+    if (value != PT_GEOM_AUTO && value != PT_GEOM_LDS && value != PT_GEOM_SCALAR && value != PT_GEOM_BVH)
       return fail(c, PT_ERR_INVALID, "pt_set_option: bad geometry path %d", value);
     c->geom_policy = value;
     return PT_OK;
@@ -665,10 +757,10 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
 
 PT_API int pt_tune(pt_ctx* c, uint32_t n_passes) {
   if (!c || n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_tune: bad argument");
-  if (c->geom_policy != PT_GEOM_AUTO || c->n_spheres > PT_MAX_SPHERES_LDS) return PT_OK; // nothing to decide
+  if (c->geom_policy != PT_GEOM_AUTO || !c->have_spheres || c->n_trials < 2) return PT_OK; // nothing to decide
   c->geom_tuned = 0;
   c->trial_state = 0;
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 1 + c->n_trials; k++) {
     int rc = pt_render_passes(c, n_passes);
     if (rc != PT_OK) return rc;
   }

@@ -2,6 +2,8 @@
 // camera derivation, the reference's built-in scene, the f32 narrowing, the f64 pick ray.
 #include "pt_host.hpp"
 
+#include "pt_bvh.hpp"
+
 #include <new>
 
 #define PT_API extern "C" __attribute__((visibility("default")))
@@ -121,6 +123,39 @@ static pt::Sphere from_host(const PtHostSphere& h) {
   s.material.refraction_index = h.refraction_index;
   s.uuid = h.uuid;
   return s;
+}
+
+// the hierarchy of PT_GEOM_BVH exactly as pt_set_spheres (pt_api.hip) builds and uploads it
+PT_API int pt_build_bvh(const PtSphere* s, uint32_t n, float* nodes, size_t node_floats, float* slots,
+                        size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
+                        uint32_t* counts5) {
+  if (!s && n) return PT_ERR_INVALID;
+  std::vector<float> geom((size_t)n * 4), radii(n);
+  bool regular = true;
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) {
+      regular = regular && (std::fabs(s[i].center[k]) < 1e15f);
+      geom[4 * (size_t)i + k] = s[i].center[k];
+    }
+    regular = regular && (std::fabs(s[i].radius) < 1e15f);
+    geom[4 * (size_t)i + 3] = s[i].radius * s[i].radius;
+    radii[i] = s[i].radius;
+  }
+  ptbvh::Bvh b;
+  if (!regular || !ptbvh::build(geom.data(), radii.data(), n, &b)) return PT_ERR_NOT_READY;
+  if (counts5) {
+    counts5[0] = b.n_nodes; counts5[1] = b.n_slots; counts5[2] = b.n_tree_slots;
+    counts5[3] = b.n_outliers; counts5[4] = b.depth;
+  }
+  if (margin4) { for (int k = 0; k < 3; k++) margin4[k] = b.c0[k]; margin4[3] = b.s0; }
+  b.nodes.resize((size_t)b.n_nodes * 8); // without the spare entry the kernels read past the walk
+  if ((nodes && node_floats < b.nodes.size()) || (slots && slot_floats < b.slots.size()) ||
+      (slot_index && n_index < b.slot_index.size()))
+    return PT_ERR_CAPACITY;
+  if (nodes) std::copy(b.nodes.begin(), b.nodes.end(), nodes);
+  if (slots) std::copy(b.slots.begin(), b.slots.end(), slots);
+  if (slot_index) std::copy(b.slot_index.begin(), b.slot_index.end(), slot_index);
+  return PT_OK;
 }
 
 PT_API int pt_narrow_spheres(const PtHostSphere* in, uint32_t n, PtSphere* out) {

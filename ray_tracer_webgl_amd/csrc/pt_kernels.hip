@@ -166,16 +166,28 @@ using namespace ptd;
 // HAVE_LDS   : an LDS copy of the list exists (n <= 10 232) and serves every PER-LANE indexed
 //              read (exact phase, tail mode, shading) whichever way the scan reads; without it
 //              (lists beyond the 160 KiB LDS) those gathers go to global memory.
-template <bool SCAN_LDS, bool HAVE_LDS>
+// BVH        : PHASE 1 walks the culling hierarchy of pt_bvh.hpp instead of the whole list (see
+//              the note at the traversal).  HAVE_LDS then means "nodes and slots are staged in
+//              LDS"; list-order reads (tail mode, PHASE 3, shading) go to the global copy.
+template <bool SCAN_LDS, bool HAVE_LDS, bool BVH = false>
 __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   static_assert(HAVE_LDS || !SCAN_LDS, "an LDS scan needs the LDS copy");
+  static_assert(!BVH || !SCAN_LDS, "the hierarchy kernels scan list-order data with scalar loads");
   extern __shared__ float4 s_geom[];
   const float4* __restrict__ g_geom = reinterpret_cast<const float4*>(A.geom);
+  const float4* __restrict__ g_nodes = reinterpret_cast<const float4*>(A.bvh_nodes);
+  const float4* __restrict__ g_slots = reinterpret_cast<const float4*>(A.bvh_slots);
 
   // ---- copy the (already padded, {cx,cy,cz,r*r}) geometry into LDS once per workgroup --------
-  if constexpr (HAVE_LDS) {
+  if constexpr (HAVE_LDS && !BVH) {
     const uint32_t n_padded = PT_LDS_ENTRIES(A.n_spheres);
     for (uint32_t i = threadIdx.x; i < n_padded; i += blockDim.x) s_geom[i] = g_geom[i];
+    __syncthreads();
+  }
+  if constexpr (HAVE_LDS && BVH) { // [2 * n_nodes node halves][n_slots slots]
+    const uint32_t n_a = 2u * A.n_nodes;
+    for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) s_geom[i] = g_nodes[i];
+    for (uint32_t i = threadIdx.x; i < A.n_slots; i += blockDim.x) s_geom[n_a + i] = g_slots[i];
     __syncthreads();
   }
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -192,12 +204,22 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   };
   // per-lane index (exact phase, tail mode, shading)
   auto geom_at = [&](uint32_t i) -> float4 {
-    if constexpr (HAVE_LDS) {
+    if constexpr (HAVE_LDS && !BVH) {
       return s_geom[i];
     } else {
       return g_geom[i];
     }
   };
+  // hierarchy reads (per-lane index)
+  auto node_half = [&](uint32_t i) -> float4 { // i = 2*node (+1)
+    if constexpr (HAVE_LDS) return s_geom[i];
+    else return g_nodes[i];
+  };
+  auto slot_at = [&](uint32_t i) -> float4 {
+    if constexpr (HAVE_LDS) return s_geom[2u * A.n_nodes + i];
+    else return g_slots[i];
+  };
+  const_f4v* c_slots = (const_f4v*)A.bvh_slots;
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n_spheres = A.n_spheres;
@@ -377,7 +399,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     tl_iters++;
     if (__ballot(exhausted) != 0ull) { if (!tl_dry) tl_dry = __builtin_amdgcn_s_memrealtime(); tl_dry_iters++; }
 #endif
-    const bool coop = (n_live <= PT_COOP_MAX_LIVE) && (__ballot(alive && !fast) == 0ull);
+    const bool coop = (n_live <= (int)A.coop_max_live) && (__ballot(alive && !fast) == 0ull);
     if (coop) {
 #ifdef PT_TIMELINE
       if (!tl_coop) tl_coop = __builtin_amdgcn_s_memrealtime();
@@ -438,6 +460,172 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     uint32_t lit_from = fast ? 0xffffffffu : 0u; // first sphere index PHASE 3 must take over
     const bool scan_lane = alive && fast;
 
+#define PT_TEST(G, HB, CC, DISC)                                  \
+  float HB, CC, DISC;                                             \
+  {                                                               \
+    V3 oc = mk(o.x - G.x, o.y - G.y, o.z - G.z);                  \
+    HB = dot3(oc, d);                                             \
+    CC = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -G.w))); \
+    DISC = fma_(-a, CC, HB * HB);                                 \
+  }
+
+    if constexpr (BVH) {
+      // PHASE 1 (hierarchy).  hit_world's result for a regular ray is the lexicographic minimum
+      // of (v_i, -i) over the spheres that pass hit_sphere (note above), so the ORDER in which
+      // spheres are looked at is free and spheres that cannot pass need not be looked at.  A
+      // sphere can pass only if its fp32 discriminant is >= 0, and then the ray's half-line
+      // comes within |r| + sqrt(E) of the centre, E = u (18 |o-C|^2 + 7 r^2), u = 2^-24 (forward
+      // error of PT_TEST; the `behind` rule only removes spheres).  Every box of the tree
+      // (pt_bvh.hpp, rounded outward) is therefore inflated by a per-ray margin
+      //     m = 1.25e-3 (|o - c0|_1 + s0) + 2.5e-7 |o|_1 + 1e-6     >= sqrt(E) + slab rounding
+      // (|o-C| <= |o-c0| + |C-c0|, |C-c0| + |r| <= s0; sqrt(18 u) = 1.04e-3, sqrt(7 u) = 6.5e-4;
+      // the second term covers the rounding of -o/d in the fused slab form, the third keeps m
+      // positive for degenerate scenes) and tested with a slab test whose comparison carries a
+      // relative slack of 1e-6 >= 6u.  Reciprocal directions are clamped to +-1e18: a component
+      // that small moves the ray by < 1e-13 over t <= MAX_T, far inside m, and the clamp keeps
+      // every product finite (no 0 * inf).  A box that fails the inflated test contains no
+      // sphere that could pass; a leaf that survives runs the LITERAL test on its four slots.
+      // Far-out giants (ground spheres) are not in the tree: they are tested for every ray.
+      //
+      // Each lane walks the tree on its own (depth-first order with skip links: next = hit ?
+      // i + 1 : skip[i]); leaves are queued (8 x 16 bit) and processed in a second lockstep
+      // loop so that node steps and leaf steps do not serialise against each other.
+      uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_cnt = 0;
+      const uint32_t n_nodes = A.n_nodes;
+
+      auto eval_slot = [&](uint32_t pos) {
+        const float4 g = slot_at(pos);
+        PT_TEST(g, half_b, c, disc)
+        (void)c;
+        const float sqrtd = __builtin_sqrtf(disc);
+        float v = (-half_b - sqrtd) / a;             // :158
+        if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; // :159-160
+        const int idx = (int)A.bvh_slot_index[pos];
+        // order-free form of the shader's acceptance: smaller root wins, equal roots go to the
+        // later sphere (hit == -1 loses to everything, so v == MAX_T is accepted as in :159)
+        if (!(v < PT_MIN_T) && (v < closest || (v == closest && idx > hit))) {
+          closest = v;
+          hit = idx;
+        }
+      };
+      // pops and evaluates queued candidates while more than `keep` are queued (lockstep)
+      auto drain_to = [&](uint32_t keep) {
+        while (__ballot(q_cnt > keep) != 0ull) {
+#ifdef PT_TIMELINE
+          tl_p2_iters++;
+#endif
+          if (q_cnt > keep) {
+            const uint32_t pp = q0 & 0xffffu;
+            q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
+            q1 = __builtin_amdgcn_alignbit(q2, q1, 16);
+            q2 >>= 16;
+            q_cnt--;
+            eval_slot(pp);
+          }
+        }
+      };
+      auto note_slot = [&](uint32_t pos, float half_b, float c) {
+        if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
+        q2 = __builtin_amdgcn_alignbit(q2, q1, 16);
+        q1 = __builtin_amdgcn_alignbit(q1, q0, 16);
+        q0 = (q0 << 16) | pos;
+        q_cnt++;
+      };
+#define PT_SLOT_GROUP(C0, C1, C2, C3, BASE, ACTIVE)                                 \
+  {                                                                               \
+    PT_TEST(C0, hb0, cc0, ds0)                                                    \
+    PT_TEST(C1, hb1, cc1, ds1)                                                    \
+    PT_TEST(C2, hb2, cc2, ds2)                                                    \
+    PT_TEST(C3, hb3, cc3, ds3)                                                    \
+    const float dsmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ds0, ds1), ds2), ds3); \
+    if ((ACTIVE) && dsmax >= 0.0f) { /* padding slots have ds = -inf */           \
+      if (!(ds0 < 0.0f)) note_slot((BASE) + 0u, hb0, cc0);                        \
+      if (!(ds1 < 0.0f)) note_slot((BASE) + 1u, hb1, cc1);                        \
+      if (!(ds2 < 0.0f)) note_slot((BASE) + 2u, hb2, cc2);                        \
+      if (!(ds3 < 0.0f)) note_slot((BASE) + 3u, hb3, cc3);                        \
+    }                                                                             \
+  }
+      // the outliers (at most 8 groups of four) start out in the leaf queue of every scanning lane
+      if (scan_lane) {
+        for (uint32_t i = A.n_slots; i > A.n_tree_slots; i -= 4u) {
+          l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
+          l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
+          l1 = __builtin_amdgcn_alignbit(l1, l0, 16);
+          l0 = (l0 << 16) | ((i - 4u) >> 2);
+          l_cnt++;
+        }
+      }
+
+      const float mrg = fma_(1.25e-3f,
+                             ((__builtin_fabsf(o.x - A.bvh_c0[0]) + __builtin_fabsf(o.y - A.bvh_c0[1])) +
+                              __builtin_fabsf(o.z - A.bvh_c0[2])) + A.bvh_s0,
+                             fma_(2.5e-7f, (__builtin_fabsf(o.x) + __builtin_fabsf(o.y)) + __builtin_fabsf(o.z), 1e-6f));
+      const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f);
+      const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f);
+      const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f);
+      // plane parameters t = lo * i - (o + m) * i  and  t = hi * i - (o - m) * i
+      const float ahx = -((o.x + mrg) * ix), alx = -((o.x - mrg) * ix);
+      const float ahy = -((o.y + mrg) * iy), aly = -((o.y - mrg) * iy);
+      const float ahz = -((o.z + mrg) * iz), alz = -((o.z - mrg) * iz);
+
+      uint32_t cur = scan_lane ? 0u : n_nodes;
+      for (;;) {
+        for (;;) {
+          // loop-carried state changes through selects only; the one real branch is the push
+          const bool act = (cur < n_nodes) & (l_cnt < 8u);
+          if (__ballot(act) == 0ull) break;
+#ifdef PT_TIMELINE
+          tl_p3_entries++;
+#endif
+          // idle lanes read too (cur <= n_nodes: the node array carries one spare entry)
+          const float4 na = node_half(2u * cur);
+          const float4 nb = node_half(2u * cur + 1u);
+          const float t1x = fma_(na.x, ix, ahx), t2x = fma_(nb.x, ix, alx);
+          const float t1y = fma_(na.y, iy, ahy), t2y = fma_(nb.y, iy, aly);
+          const float t1z = fma_(na.z, iz, ahz), t2z = fma_(nb.z, iz, alz);
+          const float tn = __builtin_fmaxf(
+              __builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+              __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+          const float tf = __builtin_fminf(
+              __builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+              __builtin_fmaxf(t1z, t2z));
+          const bool through = tn <= tf * 1.000001f;
+          const uint32_t leaf = f2u(nb.w);
+          if (act && through && leaf != 0xffffffffu) {
+            l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
+            l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
+            l1 = __builtin_amdgcn_alignbit(l1, l0, 16);
+            l0 = (l0 << 16) | (leaf >> 2);
+            l_cnt++;
+          }
+          const uint32_t nxt = through ? cur + 1u : f2u(na.w);
+          cur = act ? nxt : cur;
+        }
+        while (__ballot(l_cnt != 0u) != 0ull) {
+#ifdef PT_TIMELINE
+          tl_p3_spheres++;
+#endif
+          drain_to(2u); // a leaf adds up to four candidates to a queue of six
+          const bool busy = l_cnt != 0u;
+          const uint32_t base = busy ? (l0 & 0xffffu) << 2 : 0u;
+          if (busy) {
+            l0 = __builtin_amdgcn_alignbit(l1, l0, 16);
+            l1 = __builtin_amdgcn_alignbit(l2, l1, 16);
+            l2 = __builtin_amdgcn_alignbit(l3, l2, 16);
+            l3 >>= 16;
+            l_cnt--;
+          }
+          const float4 g0 = slot_at(base), g1 = slot_at(base + 1u), g2 = slot_at(base + 2u),
+                       g3 = slot_at(base + 3u);
+          PT_SLOT_GROUP(g0, g1, g2, g3, base, busy)
+        }
+        if (__ballot(cur < n_nodes) == 0ull) break;
+      }
+#undef PT_SLOT_GROUP
+
+      // PHASE 2: exact evaluation of whatever is still queued
+      drain_to(0u);
+    } else {
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
       if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
       if (q_cnt < 6u) {
@@ -451,15 +639,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         lit_from = idx < lit_from ? idx : lit_from;
       }
     };
-
-#define PT_TEST(G, HB, CC, DISC)                                  \
-  float HB, CC, DISC;                                             \
-  {                                                               \
-    V3 oc = mk(o.x - G.x, o.y - G.y, o.z - G.z);                  \
-    HB = dot3(oc, d);                                             \
-    CC = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -G.w))); \
-    DISC = fma_(-a, CC, HB * HB);                                 \
-  }
 
 #define PT_GROUP(C0, C1, C2, C3, BASE)                                            \
   {                                                                               \
@@ -523,6 +702,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
     }
+    } // !BVH
 
     // PHASE 3: the shader's loop verbatim for whatever the queue does not cover (rare)
     {
@@ -696,6 +876,15 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar(const 
 // lists beyond the LDS (10 232 < n <= 65 528): scalar-load walk, gathers from global memory
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(const PtKernelArgs A) {
   pt_trace_body<false, false>(A);
+}
+
+// the hierarchy walk (PT_GEOM_BVH): nodes + slots staged in LDS (dynamic LDS =
+// PT_BVH_LDS_BYTES(n_nodes, n_slots)), or read from global memory / L2 when they do not fit
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh(const PtKernelArgs A) {
+  pt_trace_body<false, true, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem(const PtKernelArgs A) {
+  pt_trace_body<false, false, true>(A);
 }
 
 // --------------------------------------------------------------------------------------------

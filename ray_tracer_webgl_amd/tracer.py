@@ -94,11 +94,13 @@ class PathTracer:
             self._check(self.lib.pt_bind_accum(self._ctx, C.c_void_p(self.accum_tensor.data_ptr()), nbytes))
 
     def set_geometry_path(self, path):
-        """abi.PT_GEOM_AUTO (default: measure both once per scene) / PT_GEOM_LDS / PT_GEOM_SCALAR."""
+        """abi.PT_GEOM_AUTO (default: measure the usable paths once per scene) / PT_GEOM_LDS /
+        PT_GEOM_SCALAR / PT_GEOM_BVH."""
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_GEOMETRY_PATH, int(path)))
 
     def tune(self, n_passes):
-        """Settle PT_GEOM_AUTO now (three untimed launches of n_passes passes); clears the accumulation."""
+        """Settle PT_GEOM_AUTO now (one cold + one untimed launch of n_passes passes per usable
+        path); clears the accumulation."""
         self._check(self.lib.pt_tune(self._ctx, int(n_passes)))
         if self.accum_tensor is not None:
             self.accum_tensor.zero_()

@@ -77,6 +77,57 @@ def test_random_scenes_bit_exact(ora, seed):
     t.close()
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_bit_exact_through_the_hierarchy(ora, seed):
+    """The same kind of scenes (duplicates, concentric and negative-radius spheres, huge and tiny
+    radii, every material) with the hierarchy walk forced: whatever the tree skips must be
+    something the shader's loop would have rejected."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500]))
+    width, height = int(rng.integers(9, 150)), int(rng.integers(5, 90))
+    if n >= 400:
+        width, height = min(width, 64), min(height, 40)
+    spp, depth, passes = int(rng.integers(1, 9)), int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 4))
+    sc = random_scene(rng, n, width, height, spp, depth, passes)
+    if seed % 3 == 0:  # a spread-out field, so that the tree has something to cull
+        sc.spheres["center"] *= np.float32(rng.choice([4.0, 15.0]))
+    t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=abi.PT_GEOM_BVH)
+    ref, seg = ora.render(sc.spheres, sc.params, passes)
+    g, r = bits(got), bits(ref)
+    assert np.array_equal(g, r), "seed %d: %d of %d values differ" % (seed, (g != r).sum(), g.size)
+    st = t.stats()
+    assert st.segments == seg and st.geometry_path == abi.PT_GEOM_BVH and st.bvh_nodes > 0
+    t.close()
+
+
+def test_tie_break_order_matters_in_the_hierarchy(ora):
+    """As below, with enough filler spheres for a tree: the two coincident spheres land in tree
+    slots whose order has nothing to do with the list order, and the LATER list entry must
+    still win."""
+    base = scenes.config1(120, 72, 4, 8)
+    a = base.spheres[1:2].copy()
+    b = a.copy()
+    b["albedo"] = (0.1, 0.9, 0.1)
+    rng = np.random.default_rng(7)
+    filler = np.zeros(30, dtype=abi.SPHERE_DTYPE)
+    filler["center"] = rng.uniform(-6, 6, (30, 3)) * (1.0, 0.2, 1.0) + (0, 0.5, -6)
+    filler["radius"] = 0.3
+    filler["albedo"] = 0.6
+    imgs = []
+    for order in ((a, b), (b, a)):
+        sc = scenes.config1(120, 72, 4, 8)
+        sc.spheres = np.concatenate([base.spheres[:1], order[0], filler[:11], base.spheres[2:], filler[11:], order[1]])
+        sc.spheres["uuid"] = np.arange(len(sc.spheres))
+        sc.n_passes = 2
+        t, got = render_scene(sc, geometry_path=abi.PT_GEOM_BVH)
+        ref, seg = ora.render(sc.spheres, sc.params, 2)
+        assert np.array_equal(bits(got), bits(ref)) and t.stats().segments == seg
+        assert t.stats().geometry_path == abi.PT_GEOM_BVH
+        imgs.append(got)
+        t.close()
+    assert not np.array_equal(imgs[0], imgs[1])
+
+
 def test_tie_break_order_matters(ora):
     """Two coincident spheres with different albedo: the image depends on which one is LATER in
     the list (static/shader.frag:159 rejects only `t_max < root`), in every kernel mode."""

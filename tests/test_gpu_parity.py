@@ -117,10 +117,10 @@ def test_probe_ieee_div_sqrt_fma(pt):
 
 
 # -------------------------------------------------------------------------------- full frames
-def _check_scene(ora, sc, n_passes=None, window=None, passes_per_launch=None):
+def _check_scene(ora, sc, n_passes=None, window=None, passes_per_launch=None, geometry_path=None):
     n_passes = n_passes or sc.n_passes
     sc.n_passes = n_passes
-    t, got = render_scene(sc, passes_per_launch=passes_per_launch)
+    t, got = render_scene(sc, passes_per_launch=passes_per_launch, geometry_path=geometry_path)
     try:
         st = t.stats()
         ref, seg = ora.render(sc.spheres, sc.params, n_passes, window=window)
@@ -495,24 +495,44 @@ def test_sphere_list_beyond_lds_capacity(ora):
     t.close()
 
 
-@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_AUTO])
+@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH, abi.PT_GEOM_AUTO])
 def test_geometry_paths_are_bit_identical(ora, path):
-    """LDS walk, scalar-load walk and the autotuned choice give the same bits (and the same
-    segment counts) on scenes that exercise every phase of hit_world."""
+    """LDS walk, scalar-load walk, hierarchy walk and the autotuned choice give the same bits
+    (and the same segment counts) on scenes that exercise every phase of hit_world."""
     for sc in (scenes.default_scene(96, 54, spp=4, max_depth=8), scenes.config2(96, 54, 4, 2, 50),
                scenes.config4(48, 48, 4, 2, 50)):
         sc.n_passes = 5
-        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 5 launches: AUTO tries both
+        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 5 launches: AUTO tries them all
         ref, seg = ora.render(sc.spheres, sc.params, 5)
         assert_bit_equal(got, ref, "%s path %d" % (sc.name, path))
         st = t.stats()
         assert st.segments == seg
-        if path != abi.PT_GEOM_AUTO:
+        has_tree = len(sc.spheres) >= 16
+        assert (st.bvh_nodes > 0) == has_tree
+        if path == abi.PT_GEOM_BVH:
+            # scenes without a hierarchy (fewer than 16 spheres) fall back to the scalar walk
+            assert st.geometry_path == (abi.PT_GEOM_BVH if has_tree else abi.PT_GEOM_SCALAR)
+        elif path != abi.PT_GEOM_AUTO:
             assert st.geometry_path == path
         else:
-            assert st.geometry_tuned == 1 and st.geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR)
+            assert st.geometry_tuned == 1
+            assert st.geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR) + ((abi.PT_GEOM_BVH,) if has_tree else ())
         t.close()
     assert t.lib.pt_set_option(None, 1, 1) == abi.PT_ERR_INVALID
+
+
+def test_hierarchy_in_global_memory(ora):
+    """10 001 spheres: nodes + slots (335 KB) exceed the LDS, pt_trace_kernel_bvh_gmem walks them
+    in global memory / L2.  Window-checked against the oracle, whole frame against the list walk."""
+    sc = scenes.config5(160, 90, 2, 1, 20)
+    t, got, ref = _check_scene(ora, sc, window=(60, 84, 30, 46), geometry_path=abi.PT_GEOM_BVH)
+    st = t.stats()
+    assert st.geometry_path == abi.PT_GEOM_BVH and (2 * st.bvh_nodes + st.bvh_slots) * 16 > 160 * 1024
+    t2, got2 = render_scene(sc, geometry_path=abi.PT_GEOM_SCALAR)
+    assert_bit_equal(got, got2, "hierarchy walk vs list walk, whole frame")
+    assert t2.stats().segments == st.segments
+    t.close()
+    t2.close()
 
 
 def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):
@@ -527,7 +547,7 @@ def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):
     t.render_passes(2)
     ref, seg = ora.render(sc.spheres, sc.params, 2)
     assert_bit_equal(t.accum(), ref, "after pt_tune")
-    assert t.stats().segments == seg and t.stats().geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR)
+    assert t.stats().segments == seg and t.stats().geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH)
     t.close()
 
 

@@ -1,4 +1,4 @@
-"""Dev tool: LDS walk vs scalar-load walk of the sphere list, interleaved in one process."""
+"""Dev tool: LDS walk vs scalar-load walk vs hierarchy walk, interleaved in one process."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ray_tracer_webgl_amd import scenes
@@ -13,14 +13,20 @@ for name in sys.argv[1:] or list(cases):
     sc, n = cases[name]
     pt = PathTracer(sc.params.width, sc.params.height)
     pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(n)
-    res = {"lds": [], "scalar": []}
+    modes = {"lds": 1, "scalar": 2, "bvh": 3}
+    if len(sc.spheres) > 10232:
+        del modes["lds"]
+    res = {m: [] for m in modes}
     for rep in range(3):
-        for mode in ("lds", "scalar"):
-            pt.set_geometry_path(2 if mode == "scalar" else 1)
+        for mode in modes:
+            pt.set_geometry_path(modes[mode])
             pt.reset(); pt.render_passes(n); pt.synchronize(); pt.reset()
             t0 = time.perf_counter(); pt.render_passes(n); pt.synchronize()
             res[mode].append((time.perf_counter() - t0) * 1e3)
     segs = pt.stats().segments
-    print("%-10s %5d spheres: LDS %.1f ms  scalar %.1f ms  (scalar/LDS = %.3f)" % (
-        name, len(sc.spheres), sorted(res["lds"])[1], sorted(res["scalar"])[1], sorted(res["scalar"])[1] / sorted(res["lds"])[1]), flush=True)
+    st = pt.stats()
+    med = {m: sorted(v)[1] for m, v in res.items()}
+    print("%-10s %5d spheres (tree: %d nodes, %d slots, %d outliers, depth %d): " % (
+        name, len(sc.spheres), st.bvh_nodes, st.bvh_slots, st.bvh_outliers, st.bvh_depth) +
+        "  ".join("%s %.1f ms (%.2f Gray/s)" % (m, med[m], segs / med[m] / 1e6) for m in med), flush=True)
     pt.close()
