@@ -227,12 +227,16 @@ int pt_tune(pt_ctx* ctx, uint32_t n_passes);
  * check its invariants): nodes = 8 floats each {lo.xyz, bits(skip), hi.xyz, bits(first slot of
  * the leaf | 0xffffffff)}, slots = 4 floats each {cx, cy, cz, r*r}, slot_index = original sphere
  * index per slot (0xffffffff = padding), margin4 = {c0.xyz, s0}, counts5 = {n_nodes, n_slots,
- * n_tree_slots, n_outliers, depth}.  Array pointers may be NULL (sizes only); capacities are in
- * elements.  Returns PT_ERR_NOT_READY when the scene gets no hierarchy (fewer than 16 spheres,
- * non-finite values), PT_ERR_CAPACITY when an array is too small. */
+ * n_tree_slots, n_outliers, depth}; nodes16 = the packed form the kernels read, 4 words per node
+ * for n_nodes + 1 nodes {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z as binary16 of (x - c0) * kscale rounded
+ * outward, skip | leaf_number << 16}; nodes32 = the fp32 form small scenes use, 8 floats per
+ * node for n_nodes + 1 nodes {lo - c0, bits(skip), hi - c0, bits(leaf_number)}.  Array pointers
+ * may be NULL (sizes only); capacities are in elements.  Returns PT_ERR_NOT_READY when the scene gets no hierarchy (fewer than 16
+ * spheres, non-finite values), PT_ERR_CAPACITY when an array is too small. */
 int pt_build_bvh(const PtSphere* spheres, uint32_t n, float* nodes, size_t node_floats, float* slots,
                  size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
-                 uint32_t* counts5);
+                 uint32_t* counts5, uint32_t* nodes16, size_t n_words16, float* kscale,
+                 float* nodes32, size_t n_floats32);
 const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -66,12 +66,13 @@ struct pt_ctx {
   double trial_samples[3] = {0.0, 0.0, 0.0};
   // culling hierarchy (PT_GEOM_BVH), rebuilt by pt_set_spheres; absent for tiny / irregular scenes
   bool have_bvh = false;
-  float* d_bvh_nodes = nullptr;
+  uint32_t* d_bvh_nodes = nullptr;
+  float* d_bvh_nodes32 = nullptr;
   float* d_bvh_slots = nullptr;
   uint32_t* d_bvh_index = nullptr;
   size_t bvh_node_cap = 0, bvh_slot_cap = 0;
   uint32_t bvh_n_nodes = 0, bvh_n_slots = 0, bvh_n_tree_slots = 0, bvh_n_outliers = 0, bvh_depth = 0;
-  float bvh_c0[3] = {0, 0, 0}, bvh_s0 = 0;
+  float bvh_c0[3] = {0, 0, 0}, bvh_s0 = 0, bvh_kinv = 1;
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -253,6 +254,8 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -268,6 +271,7 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_geom) (void)hipFree(c->d_geom);
   if (c->d_mat) (void)hipFree(c->d_mat);
   if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
+  if (c->d_bvh_nodes32) (void)hipFree(c->d_bvh_nodes32);
   if (c->d_bvh_slots) (void)hipFree(c->d_bvh_slots);
   if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
   if (c->own_accum) (void)hipFree(c->own_accum);
@@ -348,11 +352,13 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   }
   c->have_bvh = false;
   if (have_bvh) {
-    if (bvh.nodes.size() > c->bvh_node_cap) {
+    if (bvh.nodes16.size() > c->bvh_node_cap) {
       if (c->d_bvh_nodes) PT_HIP(c, hipFree(c->d_bvh_nodes));
-      c->d_bvh_nodes = nullptr; c->bvh_node_cap = 0;
-      PT_HIP(c, hipMalloc(&c->d_bvh_nodes, bvh.nodes.size() * sizeof(float)));
-      c->bvh_node_cap = bvh.nodes.size();
+      if (c->d_bvh_nodes32) PT_HIP(c, hipFree(c->d_bvh_nodes32));
+      c->d_bvh_nodes = nullptr; c->d_bvh_nodes32 = nullptr; c->bvh_node_cap = 0;
+      PT_HIP(c, hipMalloc(&c->d_bvh_nodes, bvh.nodes16.size() * sizeof(uint32_t)));
+      PT_HIP(c, hipMalloc(&c->d_bvh_nodes32, bvh.nodes32.size() * sizeof(float)));
+      c->bvh_node_cap = bvh.nodes16.size();
     }
     if (bvh.slots.size() > c->bvh_slot_cap) {
       if (c->d_bvh_slots) PT_HIP(c, hipFree(c->d_bvh_slots));
@@ -362,7 +368,8 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
       PT_HIP(c, hipMalloc(&c->d_bvh_index, bvh.slot_index.size() * sizeof(uint32_t)));
       c->bvh_slot_cap = bvh.slots.size();
     }
-    PT_HIP(c, hipMemcpy(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_bvh_nodes, bvh.nodes16.data(), bvh.nodes16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_bvh_nodes32, bvh.nodes32.data(), bvh.nodes32.size() * sizeof(float), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_bvh_slots, bvh.slots.data(), bvh.slots.size() * sizeof(float), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_bvh_index, bvh.slot_index.data(), bvh.slot_index.size() * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
@@ -370,6 +377,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     c->bvh_n_outliers = bvh.n_outliers; c->bvh_depth = bvh.depth;
     for (int k = 0; k < 3; k++) c->bvh_c0[k] = bvh.c0[k];
     c->bvh_s0 = bvh.s0;
+    c->bvh_kinv = bvh.kinv;
     c->have_bvh = true;
   }
   c->n_spheres = n;
@@ -553,6 +561,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.coop_max_live = 16;
   if (path == PT_GEOM_BVH) {
     A.bvh_nodes = c->d_bvh_nodes;
+    A.bvh_nodes32 = c->d_bvh_nodes32;
     A.bvh_slots = c->d_bvh_slots;
     A.bvh_slot_index = c->d_bvh_index;
     A.n_nodes = c->bvh_n_nodes;
@@ -560,15 +569,21 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     A.n_slots = c->bvh_n_slots;
     for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
     A.bvh_s0 = c->bvh_s0;
+    A.bvh_kinv = c->bvh_kinv;
     // tail mode costs ~n/64 rounds per live ray, the walk a roughly constant ~1500 issue slots
     // per wave: the turn-around only pays for the last few rays of a wave
     uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
     uint32_t lim = 1500u / per_ray;
     A.coop_max_live = lim > 16u ? 16u : lim;
-    size_t need = PT_BVH_LDS_BYTES(c->bvh_n_nodes, c->bvh_n_slots);
-    if (need <= (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16) {
-      lds = need;
+    const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
+    const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
+    const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
+    if (need_all <= lds_max) {
+      lds = need_all;
       kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh);
+    } else if (need_nodes <= lds_max) {
+      lds = need_nodes;
+      kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes);
     } else {
       kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem);
     }

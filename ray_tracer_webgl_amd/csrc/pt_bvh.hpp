@@ -17,11 +17,20 @@
 // spheres, hence a few far-out giants (a ground sphere of radius 1000) would inflate everything:
 // such OUTLIERS are kept out of the tree and are tested for every ray, like the reference does.
 //
-// Layout produced (all arrays are uploaded as they are):
+// Layout produced:
 //   nodes : n_nodes x 8 floats  {lo.x, lo.y, lo.z, bits(skip), hi.x, hi.y, hi.z, bits(leaf)}
 //           in depth-first order: the left child of node i is i+1; `skip` is the node that
 //           follows i's subtree (n_nodes ends the walk); leaf = first slot of a leaf (a multiple
-//           of 4) or 0xffffffff for an inner node.
+//           of 4) or 0xffffffff for an inner node.  (Host form: tests, pt_build_bvh.)
+//   nodes32 : what the kernel for small scenes reads — {lo - c0, bits(skip), hi - c0,
+//           bits(leaf_number)}, fp32 rounded outward, plus the spare node described below.
+//   nodes16 : what the kernels for larger scenes read — the same nodes packed into 16 bytes: six binary16 box
+//           coordinates {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z} in the frame (x - c0) * kscale
+//           (kscale a power of two), each rounded OUTWARD, then skip | leaf_number << 16
+//           (leaf_number = first slot / 4, 0xffff for an inner node); one spare node at the
+//           end, which lanes that have finished their walk keep reading.  Coarser boxes only
+//           cost a few extra visits: at the rim of the scene a binary16 step is s0 / 2048,
+//           below the per-ray margin of 1.25e-3 s0.
 //   slots : n_slots x {cx, cy, cz, r*r}; four slots per leaf, unused ones hold a sphere that can
 //           never pass (r*r = -inf -> discriminant = -inf); the outliers follow the leaves, also
 //           in groups of four.  slots[n_tree_slots .. n_slots) is the brute-force part.
@@ -42,6 +51,9 @@ constexpr uint32_t kInner = 0xffffffffu;
 
 struct Bvh {
   std::vector<float> nodes;        // 8 per node
+  std::vector<uint32_t> nodes16;   // 4 per node, n_nodes + 1 records
+  std::vector<float> nodes32;      // 8 per node, n_nodes + 1 records: fp32 boxes in the frame x - c0
+  float kscale = 1.0f, kinv = 1.0f;  // box frame: (x - c0) * kscale, kinv = 1 / kscale
   std::vector<float> slots;        // 4 per slot
   std::vector<uint32_t> slot_index;
   uint32_t n_nodes = 0, n_slots = 0, n_tree_slots = 0, n_outliers = 0, depth = 0;
@@ -73,6 +85,52 @@ inline float round_up(double v) {
 }
 inline uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float from_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// ---- binary16 with directed rounding (no _Float16 on the host side) ---------------------------
+inline float half_to_float(uint16_t h) {
+  const uint32_t sgn = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 1023u;
+  float v;
+  if (e == 0) v = std::ldexp((float)m, -24);
+  else if (e == 31) v = m ? std::numeric_limits<float>::quiet_NaN() : std::numeric_limits<float>::infinity();
+  else v = std::ldexp((float)(m + 1024u), (int)e - 25);
+  return sgn ? -v : v;
+}
+inline uint16_t half_next_up(uint16_t h) {    // next value towards +inf
+  if (h == 0x8000u) h = 0;
+  return (h & 0x8000u) ? (uint16_t)(h - 1) : (uint16_t)(h + 1);
+}
+inline uint16_t half_next_down(uint16_t h) {  // next value towards -inf
+  if (h == 0) h = 0x8000u;
+  return (h & 0x8000u) ? (uint16_t)(h + 1) : (uint16_t)(h - 1);
+}
+inline uint16_t half_nearest(double v) {
+  if (v == 0.0 || v != v) return 0;
+  const uint16_t sgn = v < 0 ? 0x8000u : 0;
+  double a = std::fabs(v);
+  if (a >= 65504.0) return (uint16_t)(sgn | 0x7bffu);
+  int e;
+  const double f = std::frexp(a, &e);  // a = f * 2^e, f in [0.5, 1)
+  int E = e - 1;
+  uint32_t bits16;
+  if (E < -14) {
+    bits16 = (uint32_t)std::llround(std::ldexp(a, 24));
+  } else {
+    uint32_t m = (uint32_t)std::llround((2.0 * f - 1.0) * 1024.0);
+    if (m == 1024u) { m = 0; E++; }
+    bits16 = ((uint32_t)(E + 15) << 10) | m;
+  }
+  return (uint16_t)(sgn | bits16);
+}
+inline uint16_t half_round_down(double v) {
+  uint16_t h = half_nearest(v);
+  while ((double)half_to_float(h) > v) h = half_next_down(h);
+  return h;
+}
+inline uint16_t half_round_up(double v) {
+  uint16_t h = half_nearest(v);
+  while ((double)half_to_float(h) < v) h = half_next_up(h);
+  return h;
+}
 
 struct Builder {
   const float* geom;  // n x {cx, cy, cz, r*r} as the brute-force kernels read it
@@ -246,11 +304,51 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Bvh* out) 
   out->slots.reserve((size_t)n * 8);
   B.build(0, (uint32_t)B.order.size(), 1);
   out->n_nodes = (uint32_t)(out->nodes.size() / 8);
-  // one spare node behind the tree: lanes that have finished their walk (cur == n_nodes) still
-  // issue the loads of the lockstep loop
+  if (out->n_nodes > 0xfffeu) return false;  // 16-bit skip links
+  // ---- the packed form the kernels read --------------------------------------------------------
   {
-    const float spare[8] = {0.f, 0.f, 0.f, from_bits(out->n_nodes), 0.f, 0.f, 0.f, from_bits(kInner)};
-    out->nodes.insert(out->nodes.end(), spare, spare + 8);
+    double ext = 0.0;  // largest |box coordinate - c0|
+    for (uint32_t i = 0; i < out->n_nodes; i++)
+      for (int k = 0; k < 3; k++) {
+        ext = std::max(ext, std::fabs((double)out->nodes[8 * i + k] - (double)out->c0[k]));
+        ext = std::max(ext, std::fabs((double)out->nodes[8 * i + 4 + k] - (double)out->c0[k]));
+      }
+    int e = 0;
+    if (ext > 0) (void)std::frexp(ext, &e);  // ext < 2^e
+    const int shift = 10 - e;                // scaled coordinates stay below 2^10 (binary16: 65504)
+    out->kscale = std::ldexp(1.0f, shift);
+    out->kinv = std::ldexp(1.0f, -shift);
+    out->nodes16.resize((size_t)(out->n_nodes + 1) * 4);
+    for (uint32_t i = 0; i < out->n_nodes; i++) {
+      uint16_t h[6];
+      for (int k = 0; k < 3; k++) {
+        h[k] = half_round_down(((double)out->nodes[8 * i + k] - (double)out->c0[k]) * (double)out->kscale);
+        h[3 + k] = half_round_up(((double)out->nodes[8 * i + 4 + k] - (double)out->c0[k]) * (double)out->kscale);
+      }
+      const uint32_t skip = bits(out->nodes[8 * i + 3]), leaf = bits(out->nodes[8 * i + 7]);
+      const uint32_t leaf16 = leaf == kInner ? 0xffffu : leaf / kLeafSize;
+      out->nodes16[4 * i + 0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+      out->nodes16[4 * i + 1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+      out->nodes16[4 * i + 2] = (uint32_t)h[4] | ((uint32_t)h[5] << 16);
+      out->nodes16[4 * i + 3] = skip | (leaf16 << 16);
+    }
+    // the fp32 device form (small scenes): {lo - c0, bits(skip), hi - c0, bits(leaf number)}
+    out->nodes32.resize((size_t)(out->n_nodes + 1) * 8);
+    for (uint32_t i = 0; i < out->n_nodes; i++) {
+      for (int k = 0; k < 3; k++) {
+        out->nodes32[8 * i + k] = round_down((double)out->nodes[8 * i + k] - (double)out->c0[k]);
+        out->nodes32[8 * i + 4 + k] = round_up((double)out->nodes[8 * i + 4 + k] - (double)out->c0[k]);
+      }
+      const uint32_t leaf = bits(out->nodes[8 * i + 7]);
+      out->nodes32[8 * i + 3] = out->nodes[8 * i + 3];
+      out->nodes32[8 * i + 7] = from_bits(leaf == kInner ? 0xffffu : leaf / kLeafSize);
+    }
+    for (int k = 0; k < 8; k++) out->nodes32[8 * out->n_nodes + k] = 0.f;
+    out->nodes32[8 * out->n_nodes + 3] = from_bits(out->n_nodes);
+    out->nodes32[8 * out->n_nodes + 7] = from_bits(0xffffu);
+    // the spare node: an inner node that links to the end of the walk
+    out->nodes16[4 * out->n_nodes + 0] = 0; out->nodes16[4 * out->n_nodes + 1] = 0;
+    out->nodes16[4 * out->n_nodes + 2] = 0; out->nodes16[4 * out->n_nodes + 3] = out->n_nodes | 0xffff0000u;
   }
   // ---- the brute-force tail: outliers in ascending index order, groups of four ------------------
   for (uint32_t i = 0; i < n; i++) {

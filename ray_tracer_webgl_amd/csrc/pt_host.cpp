@@ -128,7 +128,8 @@ static pt::Sphere from_host(const PtHostSphere& h) {
 // the hierarchy of PT_GEOM_BVH exactly as pt_set_spheres (pt_api.hip) builds and uploads it
 PT_API int pt_build_bvh(const PtSphere* s, uint32_t n, float* nodes, size_t node_floats, float* slots,
                         size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
-                        uint32_t* counts5) {
+                        uint32_t* counts5, uint32_t* nodes16, size_t n_words16, float* kscale,
+                        float* nodes32, size_t n_floats32) {
   if (!s && n) return PT_ERR_INVALID;
   std::vector<float> geom((size_t)n * 4), radii(n);
   bool regular = true;
@@ -148,10 +149,14 @@ PT_API int pt_build_bvh(const PtSphere* s, uint32_t n, float* nodes, size_t node
     counts5[3] = b.n_outliers; counts5[4] = b.depth;
   }
   if (margin4) { for (int k = 0; k < 3; k++) margin4[k] = b.c0[k]; margin4[3] = b.s0; }
-  b.nodes.resize((size_t)b.n_nodes * 8); // without the spare entry the kernels read past the walk
   if ((nodes && node_floats < b.nodes.size()) || (slots && slot_floats < b.slots.size()) ||
       (slot_index && n_index < b.slot_index.size()))
     return PT_ERR_CAPACITY;
+  if (nodes16 && n_words16 < b.nodes16.size()) return PT_ERR_CAPACITY;
+  if (nodes32 && n_floats32 < b.nodes32.size()) return PT_ERR_CAPACITY;
+  if (nodes32) std::copy(b.nodes32.begin(), b.nodes32.end(), nodes32);
+  if (nodes16) std::copy(b.nodes16.begin(), b.nodes16.end(), nodes16);
+  if (kscale) *kscale = b.kscale;
   if (nodes) std::copy(b.nodes.begin(), b.nodes.end(), nodes);
   if (slots) std::copy(b.slots.begin(), b.slots.end(), slots);
   if (slot_index) std::copy(b.slot_index.begin(), b.slot_index.end(), slot_index);

@@ -39,11 +39,13 @@ struct PtKernelArgs {
   uint32_t* tile_cost;           // n_tiles: longest item (segments) per tile, feeds the next launch's order
   unsigned long long* timeline;  // dev builds (-DPT_TIMELINE) only: 8 u64 per wave; NULL otherwise
   // culling hierarchy of the PT_GEOM_BVH kernels (pt_bvh.hpp); unused (NULL / 0) by the others
-  const float* bvh_nodes;          // n_nodes x {lo.xyz, skip | hi.xyz, leaf}
+  const uint32_t* bvh_nodes;       // (n_nodes + 1) x 16 B: six binary16 box coordinates, skip | leaf << 16
+  const float* bvh_nodes32;        // (n_nodes + 1) x 32 B: {lo - c0, skip, hi - c0, leaf}, fp32 (small scenes)
   const float* bvh_slots;          // n_slots x {cx, cy, cz, r*r}: leaves (4 slots each), then the outliers
   const uint32_t* bvh_slot_index;  // n_slots: original sphere index of a slot
   uint32_t n_nodes, n_tree_slots, n_slots;
-  float bvh_c0[3], bvh_s0;         // per-ray margin = PT_BVH_MARGIN * (|o - c0|_1 + s0) + ...
+  float bvh_c0[3], bvh_s0;         // per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6
+  float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
 };
 
@@ -53,7 +55,8 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
 #define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
-#define PT_BVH_LDS_BYTES(n_nodes, n_slots) (((size_t)(n_nodes) * 2u + (size_t)(n_slots)) * 16u)
+#define PT_BVH_LDS_BYTES32(n_nodes, n_slots) ((((size_t)(n_nodes) + 1u) * 2u + (size_t)(n_slots)) * 16u)
+#define PT_BVH_LDS_BYTES16(n_nodes) (((size_t)(n_nodes) + 1u) * 16u)
 #define PT_MAX_SPHERES 65528u      // candidate queues hold 16-bit indices; beyond the LDS list the
                                    // scan reads the padded global copy (pt_trace_kernel_gmem)
 

@@ -166,16 +166,21 @@ using namespace ptd;
 // HAVE_LDS   : an LDS copy of the list exists (n <= 10 232) and serves every PER-LANE indexed
 //              read (exact phase, tail mode, shading) whichever way the scan reads; without it
 //              (lists beyond the 160 KiB LDS) those gathers go to global memory.
-// BVH        : PHASE 1 walks the culling hierarchy of pt_bvh.hpp instead of the whole list (see
-//              the note at the traversal).  HAVE_LDS then means "nodes and slots are staged in
-//              LDS"; list-order reads (tail mode, PHASE 3, shading) go to the global copy.
-template <bool SCAN_LDS, bool HAVE_LDS, bool BVH = false>
+// BVH_MODE   : 0 = none of this.  Otherwise PHASE 1 walks the culling hierarchy of pt_bvh.hpp
+//              instead of the whole list (see the note at the traversal): 1 = nodes and slots
+//              staged in LDS, 2 = nodes in LDS, slots in global memory / L2, 3 = both in global
+//              memory.  List-order reads (tail mode, PHASE 3, shading) go to the global copy.
+template <bool SCAN_LDS, bool HAVE_LDS, int BVH_MODE = 0>
 __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
+  constexpr bool BVH = BVH_MODE != 0;
+  constexpr bool NODES_LDS = BVH_MODE == 1 || BVH_MODE == 2;
+  constexpr bool SLOTS_LDS = BVH_MODE == 1;
   static_assert(HAVE_LDS || !SCAN_LDS, "an LDS scan needs the LDS copy");
-  static_assert(!BVH || !SCAN_LDS, "the hierarchy kernels scan list-order data with scalar loads");
+  static_assert(!BVH || (!SCAN_LDS && !HAVE_LDS), "the hierarchy kernels read list-order data from global memory");
   extern __shared__ float4 s_geom[];
   const float4* __restrict__ g_geom = reinterpret_cast<const float4*>(A.geom);
-  const float4* __restrict__ g_nodes = reinterpret_cast<const float4*>(A.bvh_nodes);
+  const uint4* __restrict__ g_nodes = reinterpret_cast<const uint4*>(A.bvh_nodes);
+  const float4* __restrict__ g_nodes32 = reinterpret_cast<const float4*>(A.bvh_nodes32);
   const float4* __restrict__ g_slots = reinterpret_cast<const float4*>(A.bvh_slots);
 
   // ---- copy the (already padded, {cx,cy,cz,r*r}) geometry into LDS once per workgroup --------
@@ -184,10 +189,16 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     for (uint32_t i = threadIdx.x; i < n_padded; i += blockDim.x) s_geom[i] = g_geom[i];
     __syncthreads();
   }
-  if constexpr (HAVE_LDS && BVH) { // [2 * n_nodes node halves][n_slots slots]
-    const uint32_t n_a = 2u * A.n_nodes;
-    for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) s_geom[i] = g_nodes[i];
+  if constexpr (BVH_MODE == 1) { // [2 * (n_nodes + 1) halves of fp32 nodes][n_slots slots]
+    const uint32_t n_a = 2u * (A.n_nodes + 1u);
+    for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) s_geom[i] = g_nodes32[i];
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += blockDim.x) s_geom[n_a + i] = g_slots[i];
+    __syncthreads();
+  }
+  if constexpr (BVH_MODE == 2) { // [n_nodes + 1 packed nodes]
+    const uint32_t n_a = A.n_nodes + 1u;
+    uint4* s_nodes = reinterpret_cast<uint4*>(s_geom);
+    for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) s_nodes[i] = g_nodes[i];
     __syncthreads();
   }
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -211,12 +222,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
   };
   // hierarchy reads (per-lane index)
-  auto node_half = [&](uint32_t i) -> float4 { // i = 2*node (+1)
-    if constexpr (HAVE_LDS) return s_geom[i];
+  auto node_at = [&](uint32_t i) -> uint4 { // packed nodes (modes 2, 3)
+    if constexpr (NODES_LDS) return reinterpret_cast<const uint4*>(s_geom)[i];
     else return g_nodes[i];
   };
   auto slot_at = [&](uint32_t i) -> float4 {
-    if constexpr (HAVE_LDS) return s_geom[2u * A.n_nodes + i];
+    if constexpr (SLOTS_LDS) return s_geom[2u * (A.n_nodes + 1u) + i];
     else return g_slots[i];
   };
   const_f4v* c_slots = (const_f4v*)A.bvh_slots;
@@ -477,20 +488,24 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // comes within |r| + sqrt(E) of the centre, E = u (18 |o-C|^2 + 7 r^2), u = 2^-24 (forward
       // error of PT_TEST; the `behind` rule only removes spheres).  Every box of the tree
       // (pt_bvh.hpp, rounded outward) is therefore inflated by a per-ray margin
-      //     m = 1.25e-3 (|o - c0|_1 + s0) + 2.5e-7 |o|_1 + 1e-6     >= sqrt(E) + slab rounding
+      //     m = 1.25e-3 (|o - c0|_1 + s0) + 1e-6     >= sqrt(E) + slab rounding
       // (|o-C| <= |o-c0| + |C-c0|, |C-c0| + |r| <= s0; sqrt(18 u) = 1.04e-3, sqrt(7 u) = 6.5e-4;
-      // the second term covers the rounding of -o/d in the fused slab form, the third keeps m
-      // positive for degenerate scenes) and tested with a slab test whose comparison carries a
-      // relative slack of 1e-6 >= 6u.  Reciprocal directions are clamped to +-1e18: a component
-      // that small moves the ray by < 1e-13 over t <= MAX_T, far inside m, and the clamp keeps
-      // every product finite (no 0 * inf).  A box that fails the inflated test contains no
-      // sphere that could pass; a leaf that survives runs the LITERAL test on its four slots.
-      // Far-out giants (ground spheres) are not in the tree: they are tested for every ray.
+      // the 20 % on top cover the roundings of o - c0, (o - c0 +- m) / d and of the fused slab
+      // form, each of relative size u; 1e-6 keeps m positive for degenerate scenes) and tested
+      // with a slab test whose comparison carries a relative slack of 1e-6 >= 6u.  The boxes
+      // are stored as binary16 in the frame (x - c0) * k, rounded outward (pt_bvh.hpp), and
+      // enter the fused multiply-add directly (v_fma_mix_f32).  Reciprocal directions are
+      // clamped to +-1e18: a component that small moves the ray by < 1e-13 over t <= MAX_T, far
+      // inside m, and the clamp keeps every product finite (no 0 * inf).  A box that fails the
+      // inflated test contains no sphere that could pass; a leaf that survives runs the LITERAL
+      // test on its four slots.  Far-out giants (ground spheres) are not in the tree: they sit
+      // in every lane's leaf queue from the start.
       //
       // Each lane walks the tree on its own (depth-first order with skip links: next = hit ?
       // i + 1 : skip[i]); leaves are queued (8 x 16 bit) and processed in a second lockstep
       // loop so that node steps and leaf steps do not serialise against each other.
       uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_cnt = 0;
+      uint32_t q3 = 0; // this path queues up to EIGHT candidates (q0..q3)
       const uint32_t n_nodes = A.n_nodes;
 
       auto eval_slot = [&](uint32_t pos) {
@@ -518,7 +533,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             const uint32_t pp = q0 & 0xffffu;
             q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
             q1 = __builtin_amdgcn_alignbit(q2, q1, 16);
-            q2 >>= 16;
+            q2 = __builtin_amdgcn_alignbit(q3, q2, 16);
+            q3 >>= 16;
             q_cnt--;
             eval_slot(pp);
           }
@@ -526,6 +542,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       };
       auto note_slot = [&](uint32_t pos, float half_b, float c) {
         if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
+        q3 = __builtin_amdgcn_alignbit(q3, q2, 16);
         q2 = __builtin_amdgcn_alignbit(q2, q1, 16);
         q1 = __builtin_amdgcn_alignbit(q1, q0, 16);
         q0 = (q0 << 16) | pos;
@@ -545,28 +562,27 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       if (!(ds3 < 0.0f)) note_slot((BASE) + 3u, hb3, cc3);                        \
     }                                                                             \
   }
-      // the outliers (at most 8 groups of four) start out in the leaf queue of every scanning lane
-      if (scan_lane) {
-        for (uint32_t i = A.n_slots; i > A.n_tree_slots; i -= 4u) {
-          l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
-          l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
-          l1 = __builtin_amdgcn_alignbit(l1, l0, 16);
-          l0 = (l0 << 16) | ((i - 4u) >> 2);
-          l_cnt++;
-        }
+      // the outliers: wave-uniform walk (scalar loads), as the list kernels do for every sphere
+      for (uint32_t i = A.n_tree_slots; i < A.n_slots; i += 4u) {
+        if (i != A.n_tree_slots) drain_to(4u); // a group adds up to four candidates to a queue of eight
+        const f4v e0 = c_slots[i], e1 = c_slots[i + 1u], e2 = c_slots[i + 2u], e3 = c_slots[i + 3u];
+        PT_SLOT_GROUP(e0, e1, e2, e3, i, scan_lane)
       }
 
-      const float mrg = fma_(1.25e-3f,
-                             ((__builtin_fabsf(o.x - A.bvh_c0[0]) + __builtin_fabsf(o.y - A.bvh_c0[1])) +
-                              __builtin_fabsf(o.z - A.bvh_c0[2])) + A.bvh_s0,
-                             fma_(2.5e-7f, (__builtin_fabsf(o.x) + __builtin_fabsf(o.y)) + __builtin_fabsf(o.z), 1e-6f));
+      const float px = o.x - A.bvh_c0[0], py = o.y - A.bvh_c0[1], pz = o.z - A.bvh_c0[2];
+      const float mrg = fma_(1.25e-3f, ((__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz)) + A.bvh_s0, 1e-6f);
       const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f);
       const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f);
       const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f);
-      // plane parameters t = lo * i - (o + m) * i  and  t = hi * i - (o - m) * i
-      const float ahx = -((o.x + mrg) * ix), alx = -((o.x - mrg) * ix);
-      const float ahy = -((o.y + mrg) * iy), aly = -((o.y - mrg) * iy);
-      const float ahz = -((o.z + mrg) * iz), alz = -((o.z - mrg) * iz);
+      // plane parameters t = (lo / k) * i - (p + m) * i  and  t = (hi / k) * i - (p - m) * i
+      // (mode 1 keeps fp32 boxes, k = 1; the packed binary16 boxes of modes 2 and 3 enter the
+      // fused multiply-add directly, v_fma_mix_f32, which issues at half rate)
+      const float kinv = BVH_MODE == 1 ? 1.0f : A.bvh_kinv;
+      const float kx = ix * kinv, ky = iy * kinv, kz = iz * kinv;
+      const float ahx = -((px + mrg) * ix), alx = -((px - mrg) * ix);
+      const float ahy = -((py + mrg) * iy), aly = -((py - mrg) * iy);
+      const float ahz = -((pz + mrg) * iz), alz = -((pz - mrg) * iz);
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
       uint32_t cur = scan_lane ? 0u : n_nodes;
       for (;;) {
@@ -575,14 +591,28 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           const bool act = (cur < n_nodes) & (l_cnt < 8u);
           if (__ballot(act) == 0ull) break;
 #ifdef PT_TIMELINE
-          tl_p3_entries++;
+          tl_p3_entries++; tl_ovf_lanes += __popcll(__ballot(act));
 #endif
           // idle lanes read too (cur <= n_nodes: the node array carries one spare entry)
-          const float4 na = node_half(2u * cur);
-          const float4 nb = node_half(2u * cur + 1u);
-          const float t1x = fma_(na.x, ix, ahx), t2x = fma_(nb.x, ix, alx);
-          const float t1y = fma_(na.y, iy, ahy), t2y = fma_(nb.y, iy, aly);
-          const float t1z = fma_(na.z, iz, ahz), t2z = fma_(nb.z, iz, alz);
+          float t1x, t2x, t1y, t2y, t1z, t2z;
+          uint32_t skip, leaf;
+          if constexpr (BVH_MODE == 1) {
+            const float4 na = s_geom[2u * cur], nb = s_geom[2u * cur + 1u]; // lo.xyz skip | hi.xyz leaf
+            t1x = fma_(na.x, kx, ahx); t2x = fma_(nb.x, kx, alx);
+            t1y = fma_(na.y, ky, ahy); t2y = fma_(nb.y, ky, aly);
+            t1z = fma_(na.z, kz, ahz); t2z = fma_(nb.z, kz, alz);
+            skip = f2u(na.w);
+            leaf = f2u(nb.w);
+          } else {
+            const uint4 nd = node_at(cur);
+            const h2v b0 = __builtin_bit_cast(h2v, nd.x), b1 = __builtin_bit_cast(h2v, nd.y),
+                      b2 = __builtin_bit_cast(h2v, nd.z); // lo.x lo.y | lo.z hi.x | hi.y hi.z
+            t1x = fma_((float)b0.x, kx, ahx); t2x = fma_((float)b1.y, kx, alx);
+            t1y = fma_((float)b0.y, ky, ahy); t2y = fma_((float)b2.x, ky, aly);
+            t1z = fma_((float)b1.x, kz, ahz); t2z = fma_((float)b2.y, kz, alz);
+            skip = nd.w & 0xffffu;
+            leaf = nd.w >> 16;
+          }
           const float tn = __builtin_fmaxf(
               __builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
               __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
@@ -590,22 +620,21 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
               __builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
               __builtin_fmaxf(t1z, t2z));
           const bool through = tn <= tf * 1.000001f;
-          const uint32_t leaf = f2u(nb.w);
-          if (act && through && leaf != 0xffffffffu) {
+          if (act && through && leaf != 0xffffu) {
             l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
             l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
             l1 = __builtin_amdgcn_alignbit(l1, l0, 16);
-            l0 = (l0 << 16) | (leaf >> 2);
+            l0 = (l0 << 16) | leaf;
             l_cnt++;
           }
-          const uint32_t nxt = through ? cur + 1u : f2u(na.w);
+          const uint32_t nxt = through ? cur + 1u : skip;
           cur = act ? nxt : cur;
         }
         while (__ballot(l_cnt != 0u) != 0ull) {
 #ifdef PT_TIMELINE
           tl_p3_spheres++;
 #endif
-          drain_to(2u); // a leaf adds up to four candidates to a queue of six
+          drain_to(4u); // a leaf adds up to four candidates to a queue of eight
           const bool busy = l_cnt != 0u;
           const uint32_t base = busy ? (l0 & 0xffffu) << 2 : 0u;
           if (busy) {
@@ -881,10 +910,14 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(
 // the hierarchy walk (PT_GEOM_BVH): nodes + slots staged in LDS (dynamic LDS =
 // PT_BVH_LDS_BYTES(n_nodes, n_slots)), or read from global memory / L2 when they do not fit
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh(const PtKernelArgs A) {
-  pt_trace_body<false, true, true>(A);
+  pt_trace_body<false, false, 1>(A);
+}
+// nodes staged (dynamic LDS = (n_nodes + 1) * 16 bytes), slots read from global memory
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_nodes(const PtKernelArgs A) {
+  pt_trace_body<false, false, 2>(A);
 }
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem(const PtKernelArgs A) {
-  pt_trace_body<false, false, true>(A);
+  pt_trace_body<false, false, 3>(A);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -22,15 +22,33 @@ def build(spheres):
     counts = np.zeros(5, np.uint32)
     margin = np.zeros(4, np.float32)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = lib.pt_build_bvh(ptr, n, None, 0, None, 0, None, 0, vp(margin), vp(counts))
+    rc = lib.pt_build_bvh(ptr, n, None, 0, None, 0, None, 0, vp(margin), vp(counts), None, 0, None, None, 0)
     if rc != 0:
         return rc, None
     nodes = np.zeros((counts[0], 8), np.float32)
     slots = np.zeros((counts[1], 4), np.float32)
     index = np.zeros(counts[1], np.uint32)
-    rc = lib.pt_build_bvh(ptr, n, vp(nodes), nodes.size, vp(slots), slots.size, vp(index), index.size, vp(margin), vp(counts))
+    nodes16 = np.zeros((counts[0] + 1, 4), np.uint32)
+    kscale = C.c_float(0)
+    nodes32 = np.zeros((counts[0] + 1, 8), np.float32)
+    rc = lib.pt_build_bvh(ptr, n, vp(nodes), nodes.size, vp(slots), slots.size, vp(index), index.size, vp(margin), vp(counts),
+                          vp(nodes16), nodes16.size, C.byref(kscale), vp(nodes32), nodes32.size)
     return rc, dict(nodes=nodes, slots=slots, index=index, margin=margin, n_nodes=int(counts[0]), n_slots=int(counts[1]),
-                    n_tree_slots=int(counts[2]), n_outliers=int(counts[3]), depth=int(counts[4]))
+                    n_tree_slots=int(counts[2]), n_outliers=int(counts[3]), depth=int(counts[4]), nodes16=nodes16,
+                    kscale=float(kscale.value), nodes32=nodes32)
+
+
+def unpack32(b):
+    """fp32 device nodes -> (lo, hi) boxes in the frame x - c0, skip, leaf number"""
+    w = b["nodes32"]
+    return w[:, 0:3], w[:, 4:7], w[:, 3].view(np.uint32).astype(np.int64), w[:, 7].view(np.uint32).astype(np.int64)
+
+
+def unpack16(b):
+    """packed nodes -> (lo, hi) float32 boxes in the frame (x - c0) * kscale, skip, leaf number"""
+    w = b["nodes16"]
+    h = np.ascontiguousarray(w[:, :3]).view(np.float16).reshape(len(w), 6).astype(np.float32)  # lo.x lo.y lo.z hi.x hi.y hi.z
+    return h[:, 0:3], h[:, 3:6], (w[:, 3] & 0xFFFF).astype(np.int64), (w[:, 3] >> 16).astype(np.int64)
 
 
 def random_field(n, seed, extent=20.0, rmax=0.6, giants=1):
@@ -98,6 +116,20 @@ def test_structure(name):
         assert np.all(lo[i] <= lo[sub].min(0)) and np.all(hi[i] >= hi[sub].max(0))
         # the left child is i+1, the right child starts where the left subtree ends
         assert skip[skip[i + 1]] == skip[i]
+    # the packed form the kernels read: same links, boxes that contain the float boxes
+    lo16, hi16, skip16, leaf16 = unpack16(b)
+    k = b["kscale"]
+    assert k > 0 and np.log2(k) == np.round(np.log2(k)) and np.abs(lo16).max() <= 1024 and np.abs(hi16).max() <= 1024
+    assert np.array_equal(skip16[:-1], skip) and skip16[-1] == len(nodes) and leaf16[-1] == 0xFFFF
+    assert np.array_equal(leaf16[:-1][is_leaf], leaf[is_leaf] // 4) and np.all(leaf16[:-1][~is_leaf] == 0xFFFF)
+    c0d = b["margin"][:3].astype(np.float64)
+    assert np.all(lo16[:-1].astype(np.float64) / k + c0d <= lo) and np.all(hi16[:-1].astype(np.float64) / k + c0d >= hi)
+    # ... and not much bigger: one binary16 step at the rim of the scene
+    assert np.all(lo - (lo16[:-1] / k + c0d) <= b["margin"][3] / 1000.0 + 1e-6)
+    lo32, hi32, skip32, leaf32 = unpack32(b)
+    assert np.array_equal(skip32, skip16) and np.array_equal(leaf32, leaf16)
+    assert np.all(lo32[:-1].astype(np.float64) + c0d <= lo) and np.all(hi32[:-1].astype(np.float64) + c0d >= hi)
+    assert np.all(lo16[:-1] / np.float32(k) <= lo32[:-1]) and np.all(hi16[:-1] / np.float32(k) >= hi32[:-1])
     # the margin's reference data
     c0, s0 = b["margin"][:3].astype(np.float64), float(b["margin"][3])
     tree = index[:b["n_tree_slots"]]
@@ -151,33 +183,34 @@ def literal_disc(o, d, cs, r2):
     return disc, hb, cc
 
 
-def visited_slots(b, o, d):
-    """the kernel's walk (same formulas, fp32): boolean rays x slots, True where a slot is looked at"""
-    nodes = b["nodes"]
-    skip = nodes[:, 3].view(np.uint32).astype(np.int64)
-    leaf = nodes[:, 7].view(np.uint32)
+def visited_slots(b, o, d, packed=True):
+    """the kernel's walk (same formulas, fp32; packed binary16 boxes or the fp32 boxes of small
+    scenes): boolean rays x slots, True where a slot is looked at"""
+    lo16, hi16, skip, leaf = unpack16(b) if packed else unpack32(b)
     c0, s0 = b["margin"][:3], b["margin"][3]
-    l1 = f32(f32(f32(np.abs(f32(o[:, 0] - c0[0])) + np.abs(f32(o[:, 1] - c0[1]))) + np.abs(f32(o[:, 2] - c0[2]))) + s0)
-    lo1 = f32(f32(np.abs(o[:, 0]) + np.abs(o[:, 1])) + np.abs(o[:, 2]))
-    m = fma(f32(np.full(len(o), 1.25e-3)), l1, fma(f32(np.full(len(o), 2.5e-7)), lo1, f32(np.full(len(o), 1e-6))))
+    kinv = f32(1.0 / b["kscale"]) if packed else f32(1.0)
+    p = f32(o - c0[None, :])
+    l1 = f32(f32(f32(np.abs(p[:, 0]) + np.abs(p[:, 1])) + np.abs(p[:, 2])) + s0)
+    m = fma(f32(np.full(len(o), 1.25e-3)), l1, f32(np.full(len(o), 1e-6)))
     with np.errstate(divide="ignore"):
         inv = np.clip(f32(1.0) / d, f32(-1e18), f32(1e18)).astype(np.float32)
-    ah = -f32(f32(o + m[:, None]) * inv)
-    al = -f32(f32(o - m[:, None]) * inv)
+    kk = f32(inv * kinv)
+    ah = -f32(f32(p + m[:, None]) * inv)
+    al = -f32(f32(p - m[:, None]) * inv)
     seen = np.zeros((len(o), b["n_slots"]), bool)
     seen[:, b["n_tree_slots"]:] = True  # outliers: every ray
     cur = np.zeros(len(o), np.int64)
-    for i in range(len(nodes)):
+    for i in range(b["n_nodes"]):
         act = cur == i
         if not act.any():
             continue
-        t1 = fma(np.broadcast_to(nodes[i, 0:3], o.shape), inv, ah)
-        t2 = fma(np.broadcast_to(nodes[i, 4:7], o.shape), inv, al)
+        t1 = fma(np.broadcast_to(lo16[i], o.shape), kk, ah)
+        t2 = fma(np.broadcast_to(hi16[i], o.shape), kk, al)
         tn = np.maximum(np.minimum(t1, t2).max(1), f32(0))
         tf = np.maximum(t1, t2).min(1)
         through = tn <= f32(tf * f32(1.000001))
-        if leaf[i] != INNER:
-            seen[act & through, leaf[i]:leaf[i] + 4] = True
+        if leaf[i] != 0xFFFF:
+            seen[act & through, 4 * leaf[i]:4 * leaf[i] + 4] = True
         cur = np.where(act, np.where(through, i + 1, skip[i]), cur)
     return seen
 
@@ -224,6 +257,10 @@ def test_walk_reaches_every_sphere_that_can_pass(name):
         seen = visited_slots(b, o, d)[:, real]
         missed = can_pass & ~seen
         assert not missed.any(), (name, seed, np.argwhere(missed)[:5])
+        seen32 = visited_slots(b, o, d, packed=False)[:, real]
+        missed = can_pass & ~seen32
+        assert not missed.any(), (name, seed, "fp32 boxes", np.argwhere(missed)[:5])
+        assert seen32.sum() <= seen.sum()
         total_pass += int(can_pass.sum())
         total_seen += int(seen.sum())
     assert total_pass > 1000
