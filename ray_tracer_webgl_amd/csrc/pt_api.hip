@@ -256,6 +256,8 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -532,6 +534,11 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   if (items > 0xfffffff0ull)
     return fail(c, PT_ERR_CAPACITY, "pt_render_passes: %llu work items exceed 2^32; render fewer passes per call", items);
   A.n_items = (uint32_t)items;
+  A.fw = (float)c->width;
+  A.fh = (float)c->height;
+  A.div_per_tile = pt_div_make(64u * n_passes);
+  A.div_tiles_x = pt_div_make(A.tiles_x);
+  A.div_band_rows = pt_div_make(A.band_rows);
   A.geom = c->d_geom;
   A.mat = c->d_mat;
   A.slab = reinterpret_cast<float*>(c->d_slab);
@@ -558,6 +565,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   // per CU when the staged data takes most of the 160 KiB LDS
   size_t lds = 0;
   const void* kfn = nullptr;
+  uint32_t bvh_block = 0;
   A.coop_max_live = 16;
   if (path == PT_GEOM_BVH) {
     A.bvh_nodes = c->d_bvh_nodes;
@@ -575,18 +583,38 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
     uint32_t lim = 1500u / per_ray;
     A.coop_max_live = lim > 16u ? 16u : lim;
+    // dynamic LDS = staged scene + the parked path state of every lane of the workgroup
     const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
     const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
     const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
-    if (need_all <= lds_max) {
-      lds = need_all;
+    const size_t park1024 = (size_t)PT_PARK_DWORDS * 4 * 1024;
+    size_t scene = 0;
+    if (need_all + park1024 <= lds_max) {
+      scene = need_all;
       kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh);
-    } else if (need_nodes <= lds_max) {
-      lds = need_nodes;
+    } else if (need_nodes + park1024 <= lds_max) {
+      scene = need_nodes;
       kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes);
     } else {
       kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem);
     }
+    // workgroup size: whichever of 256 / 512 / 1024 threads puts the most waves on a CU (the
+    // staged scene is paid once per workgroup, the parked state and the VGPRs per wave)
+    int best_waves = -1;
+    for (uint32_t b = 256; b <= 1024; b *= 2) {
+      const size_t l = scene + (size_t)PT_PARK_DWORDS * 4 * b;
+      if (l > lds_max) continue;
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) continue;
+      const int waves = n * (int)(b / 64);
+      if (waves > best_waves) { best_waves = waves; bvh_block = b; }
+    }
+    if (const char* e = getenv("PT_BVH_BLOCK")) { // dev knob
+      uint32_t b = (uint32_t)atoi(e);
+      if (b == 256u || b == 512u || b == 1024u) bvh_block = b;
+    }
+    if (!bvh_block) bvh_block = 1024u;
+    lds = scene + (size_t)PT_PARK_DWORDS * 4 * bvh_block;
   } else {
     // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
     const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
@@ -595,7 +623,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
                               : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
                                           : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
   }
-  uint32_t block = lds > 40 * 1024 ? 1024u : 256u;
+  uint32_t block = bvh_block ? bvh_block : (lds > 40 * 1024 ? 1024u : 256u);
+  A.block_threads = block;
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;

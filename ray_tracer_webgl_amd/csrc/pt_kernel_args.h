@@ -15,6 +15,23 @@ struct PtMatRec {
 };
 static_assert(sizeof(PtMatRec) == 32, "PtMatRec must be 32 bytes");
 
+// Exact division of a 32-bit n by a launch-invariant d without a divide (Granlund & Montgomery):
+// q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n).  The constants are made on the host so
+// that they arrive in SGPRs; a wave-uniform division done in the kernel would be hoisted out
+// of the loop by the compiler and pin VGPRs for the kernel's lifetime.
+struct PtDiv {
+  uint32_t m, s1, s2;
+};
+static inline PtDiv pt_div_make(uint32_t d) {
+  PtDiv r;
+  uint32_t l = 0;
+  while (l < 32 && (1ull << l) < (unsigned long long)d) l++;
+  r.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+  r.s1 = l < 1 ? l : 1;
+  r.s2 = l > 0 ? l - 1 : 0;
+  return r;
+}
+
 struct PtKernelArgs {
   // uniform block, static/shader.frag:79-99 (see include/ptrace.h PtParams)
   float origin[3], horizontal[3], vertical[3], llc[3], cam_u[3], cam_v[3];
@@ -46,6 +63,9 @@ struct PtKernelArgs {
   uint32_t n_nodes, n_tree_slots, n_slots;
   float bvh_c0[3], bvh_s0;         // per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
+  uint32_t block_threads;          // blockDim.x of the launch
+  float fw, fh;                    // float(width), float(height)
+  PtDiv div_per_tile, div_tiles_x, div_band_rows;  // by 64 * n_passes, tiles_x, band_rows
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
 };
 
@@ -55,6 +75,7 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
 #define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
+#define PT_PARK_DWORDS 14u  // per-lane path state parked in LDS during the hierarchy walk
 #define PT_BVH_LDS_BYTES32(n_nodes, n_slots) ((((size_t)(n_nodes) + 1u) * 2u + (size_t)(n_slots)) * 16u)
 #define PT_BVH_LDS_BYTES16(n_nodes) (((size_t)(n_nodes) + 1u) * 16u)
 #define PT_MAX_SPHERES 65528u      // candidate queues hold 16-bit indices; beyond the LDS list the

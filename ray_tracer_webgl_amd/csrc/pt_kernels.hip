@@ -231,10 +231,20 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     else return g_slots[i];
   };
   const_f4v* c_slots = (const_f4v*)A.bvh_slots;
+  // LDS behind the staged scene: PT_PARK_DWORDS columns of blockDim.x dwords (parked path state)
+  typedef volatile uint32_t __attribute__((address_space(3))) lds_u32;
+  lds_u32* park = (lds_u32*)reinterpret_cast<uint32_t*>(s_geom) +
+                  4u * (BVH_MODE == 1 ? 2u * (A.n_nodes + 1u) + A.n_slots : (BVH_MODE == 2 ? A.n_nodes + 1u : 0u)) +
+                  threadIdx.x;
 
-  const uint32_t lane = threadIdx.x & 63u;
+  // (recomputed where needed rather than kept in a VGPR for the kernel's lifetime)
+#define lane (threadIdx.x & 63u)
+  auto div_ = [](uint32_t n, const PtDiv& dv) -> uint32_t {
+    const uint32_t t = __umulhi(dv.m, n);
+    return (t + ((n - t) >> dv.s1)) >> dv.s2;
+  };
   const uint32_t n_spheres = A.n_spheres;
-  const float fw = (float)A.width, fh = (float)A.height;
+  const float fw = A.fw, fh = A.fh;
   const V3 cam_o = mk(A.origin[0], A.origin[1], A.origin[2]);
 
   // ---- per-lane path state ---------------------------------------------------------------------
@@ -313,16 +323,16 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         } else {
           uint32_t item = (uint32_t)item64;
           uint32_t per_tile = 64u * A.n_passes;
-          uint32_t tile_pos = item / per_tile;
+          uint32_t tile_pos = div_(item, A.div_per_tile);
           uint32_t rem = item - tile_pos * per_tile;
           uint32_t tile = A.tile_order[tile_pos]; // heaviest tiles are dealt first
           uint32_t pass = rem >> 6, l = rem & 63u;
-          uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+          uint32_t ty = div_(tile, A.div_tiles_x), tx = tile - ty * A.tiles_x;
           uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
           if (px < A.width && ly < A.local_rows) {
             uint32_t y = ly;
             if (A.band_count > 1u) {
-              uint32_t b = ly / A.band_rows, r = ly - b * A.band_rows;
+              uint32_t b = div_(ly, A.div_band_rows), r = ly - b * A.band_rows;
               y = (b * A.band_count + A.band_index) * A.band_rows + r;
             }
             // static/shader.vert:8 + rasteriser: v_position at the pixel centre
@@ -406,6 +416,19 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // sooner at no cost in total throughput (the SIMD arbitrates by priority, then age).
     if (__ballot(alive && item_segs > PT_LONG_ITEM_SEGMENTS) != 0ull) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
+    // The hierarchy walk is latency-bound (per-lane LDS gathers, short dependent loops), so it
+    // wants waves, i.e. few VGPRs: the part of the path state that the walk does not touch is
+    // parked in LDS while it runs (14 dwords per lane, one conflict-free column each) and
+    // fetched back for shading.  volatile: the values must not be forwarded in registers.
+    if constexpr (BVH) {
+      lds_u32* ps = park;
+      const uint32_t st = A.block_threads;
+      ps[0 * st] = f2u(sum.x); ps[1 * st] = f2u(sum.y); ps[2 * st] = f2u(sum.z);
+      ps[3 * st] = f2u(col.x); ps[4 * st] = f2u(col.y); ps[5 * st] = f2u(col.z);
+      ps[6 * st] = f2u(seed); ps[7 * st] = f2u(st_s); ps[8 * st] = f2u(st_t);
+      ps[9 * st] = slab_index; ps[10 * st] = item_tile; ps[11 * st] = item_segs;
+      ps[12 * st] = (uint32_t)sample; ps[13 * st] = (uint32_t)depth;
+    }
 #ifdef PT_TIMELINE
     tl_iters++;
     if (__ballot(exhausted) != 0ull) { if (!tl_dry) tl_dry = __builtin_amdgcn_s_memrealtime(); tl_dry_iters++; }
@@ -562,6 +585,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       if (!(ds3 < 0.0f)) note_slot((BASE) + 3u, hb3, cc3);                        \
     }                                                                             \
   }
+#define PT_SLOT_PAIR(C0, C1, BASE, ACTIVE)                                          \
+  {                                                                               \
+    PT_TEST(C0, hb0, cc0, ds0)                                                    \
+    PT_TEST(C1, hb1, cc1, ds1)                                                    \
+    if ((ACTIVE) && __builtin_fmaxf(ds0, ds1) >= 0.0f) {                          \
+      if (!(ds0 < 0.0f)) note_slot((BASE) + 0u, hb0, cc0);                        \
+      if (!(ds1 < 0.0f)) note_slot((BASE) + 1u, hb1, cc1);                        \
+    }                                                                             \
+  }
       // the outliers: wave-uniform walk (scalar loads), as the list kernels do for every sphere
       for (uint32_t i = A.n_tree_slots; i < A.n_slots; i += 4u) {
         if (i != A.n_tree_slots) drain_to(4u); // a group adds up to four candidates to a queue of eight
@@ -644,13 +676,20 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             l3 >>= 16;
             l_cnt--;
           }
-          const float4 g0 = slot_at(base), g1 = slot_at(base + 1u), g2 = slot_at(base + 2u),
-                       g3 = slot_at(base + 3u);
-          PT_SLOT_GROUP(g0, g1, g2, g3, base, busy)
+          // two slots at a time: the leaf phase is where register pressure peaks
+          {
+            const float4 g0 = slot_at(base), g1 = slot_at(base + 1u);
+            PT_SLOT_PAIR(g0, g1, base, busy)
+          }
+          {
+            const float4 g2 = slot_at(base + 2u), g3 = slot_at(base + 3u);
+            PT_SLOT_PAIR(g2, g3, base + 2u, busy)
+          }
         }
         if (__ballot(cur < n_nodes) == 0ull) break;
       }
 #undef PT_SLOT_GROUP
+#undef PT_SLOT_PAIR
 
       // PHASE 2: exact evaluation of whatever is still queued
       drain_to(0u);
@@ -772,6 +811,16 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     } // !coop
 #undef PT_TEST
 
+    if constexpr (BVH) {
+      lds_u32* ps = park;
+      const uint32_t st = A.block_threads;
+      sum = mk(u2f(ps[0 * st]), u2f(ps[1 * st]), u2f(ps[2 * st]));
+      col = mk(u2f(ps[3 * st]), u2f(ps[4 * st]), u2f(ps[5 * st]));
+      seed = u2f(ps[6 * st]); st_s = u2f(ps[7 * st]); st_t = u2f(ps[8 * st]);
+      slab_index = ps[9 * st]; item_tile = ps[10 * st]; item_segs = ps[11 * st];
+      sample = (int)ps[12 * st]; depth = (int)ps[13 * st];
+    }
+
     // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
     if (alive) {
       item_segs++;
@@ -889,6 +938,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   }
 #endif
   (void)sample_count;
+#undef lane
 }
 
 // blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
@@ -907,9 +957,16 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(
   pt_trace_body<false, false>(A);
 }
 
+// The hierarchy kernels are latency-bound, not issue-bound: for scenes small enough that LDS
+// leaves room for them, six waves per SIMD (80 VGPRs, a handful of spills around the walk)
+// beat five with no spills (config 2: -5 %).  The kernels for larger scenes are held to four
+// waves by their LDS footprint and keep their registers.
+#ifndef PT_BVH_WAVES
+#define PT_BVH_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
 // the hierarchy walk (PT_GEOM_BVH): nodes + slots staged in LDS (dynamic LDS =
 // PT_BVH_LDS_BYTES(n_nodes, n_slots)), or read from global memory / L2 when they do not fit
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh(const PtKernelArgs A) {
   pt_trace_body<false, false, 1>(A);
 }
 // nodes staged (dynamic LDS = (n_nodes + 1) * 16 bytes), slots read from global memory
