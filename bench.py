@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-list-walk", action="store_true",
+                    help="skip the extra (untimed-region) launch that measures the reference's linear list walk")
     ap.add_argument("--cpu-strip", type=int, default=960, help="width of the CPU baseline's column strip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
@@ -165,14 +167,27 @@ def main():
         passes_per_launch_avg = args.steps / max(st.render_launches, 1)
         hbm_bytes = int(passes_per_launch_avg * local_pix * 16 + n_sph * 48)
         traffic = None
+        executed = None
+        kernel_name = {abi.PT_GEOM_LDS: "pt_trace_kernel", abi.PT_GEOM_SCALAR: "pt_trace_kernel_scalar",
+                       abi.PT_GEOM_BVH: "pt_trace_kernel_bvh"}.get(st.geometry_path, "?")
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("pt_trace_kernel_hbm_bytes_per_launch")
+                rec = json.load(open(prof))
+                if rec.get("kernel") == kernel_name:  # counters of another kernel say nothing about this one
+                    traffic = rec.get("pt_trace_kernel_hbm_bytes_per_launch")
+                    if "valu_insts_per_launch" in rec:
+                        executed = {
+                            "valu_instructions_per_launch": rec["valu_insts_per_launch"],
+                            "valu_issue_frac": round(rec["valu_issue_frac"], 4),
+                            "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this command)",
+                            "note": "wave64 VALU instructions issued x 2 cycles / (1024 SIMDs x kernel cycles): the share of "
+                                    "the chip's vector issue slots the kernel really fills",
+                        }
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": "pt_trace_kernel" if st.geometry_path == abi.PT_GEOM_LDS else "pt_trace_kernel_scalar",
+            "kernel": kernel_name,
             "geometry_path": abi.GEOM_NAMES.get(st.geometry_path, "?") + (" (autotuned)" if st.geometry_tuned else ""),
             "bound": "valu",
             "achieved": round(achieved_tf, 3),
@@ -184,7 +199,11 @@ def main():
             "avg_launch_ms": round(avg_ms, 4),
             "launches": int(st.render_launches),
             "flop_per_launch": flop_per_launch,
-            "note": "fp32 vector peak: no dense contraction on this path; 20 FLOP per ray-sphere test x %d spheres x segments" % n_sph,
+            "note": ("fp32 vector peak: no dense contraction on this path; ALGORITHMIC work = 20 FLOP per ray-sphere test x %d "
+                     "spheres x segments (SURVEY.md 8d), i.e. what the reference's loop does for these rays" % n_sph) +
+                    ("; the hierarchy walk skips tests whose outcome is provably 'miss', so frac can exceed 1 - see `executed`"
+                     if st.geometry_path == abi.PT_GEOM_BVH else ""),
+            "executed": executed,
             "hbm": {
                 "achieved": round(hbm_bytes / (avg_ms * 1e-3) / 1e9, 3) if avg_ms > 0 else 0.0,
                 "peak": HBM_PEAK_GBS,
@@ -193,6 +212,34 @@ def main():
                 "algorithmic_bytes_per_launch": hbm_bytes,
             },
         }
+        # Beside the headline (fastest path, normally the hierarchy walk): the same frame with the
+        # reference's own algorithm, the linear walk over the whole list, after the timed region.
+        list_walk = None
+        if st.geometry_path == abi.PT_GEOM_BVH and world == 1 and not args.no_list_walk:
+            pt.set_geometry_path(abi.PT_GEOM_SCALAR)
+            pt.reset()
+            run_steps(min(args.steps, ppl), 0.0)  # settle the tile order for this path
+            sync_all()
+            pt.reset()
+            sync_all()
+            tl0 = time.perf_counter()
+            run_steps(args.steps, 0.0)
+            sync_all()
+            tl1 = time.perf_counter()
+            sl = pt.stats()
+            l_ms = sl.render_kernel_ms / max(sl.render_launches, 1)
+            l_tf = FLOP_PER_SPHERE_TEST * n_sph * (sl.segments / max(sl.render_launches, 1)) / (l_ms * 1e-3) / 1e12
+            list_walk = {
+                "kernel": "pt_trace_kernel_scalar",
+                "value": round(sl.segments / (tl1 - tl0) / 1e6, 3),
+                "unit": "Mray/s",
+                "sec_to_converged_frame": round(tl1 - tl0, 4),
+                "avg_launch_ms": round(l_ms, 4),
+                "roofline_frac": round(l_tf / FP32_VALU_PEAK_TFLOPS, 4),
+                "segments": int(sl.segments),
+                "note": "every sphere tested for every ray, as static/shader.frag:175-196 does; same image bits, same segment count",
+            }
+            pt.set_geometry_path(abi.PT_GEOM_AUTO)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle
@@ -236,6 +283,7 @@ def main():
             "segments": int(segments),
             "nominal_mray_s": round(p.width * p.height * args.spp_per_step * args.steps * args.max_depth / wall / 1e6, 1),
             "roofline": roofline,
+            "list_walk": list_walk,
             "cpu_baseline": cpu,
         }
         if cpu:

@@ -61,8 +61,20 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
     traffic = pm["WRITE_SIZE"] * 1024 + 2 * pm["FETCH_SIZE"] * 1024
     out["pt_trace_kernel_hbm_bytes_per_launch"] = int(traffic)
     print("  HBM traffic per launch (WRITE_SIZE + 2*FETCH_SIZE): %.4g bytes" % traffic)
-    json.dump({"pt_trace_kernel_hbm_bytes_per_launch": int(traffic), "kernel": out.get("pmc_kernel"),
-               "workload": "bench.py --steps 16 --warmup 16 (config 2, 16 passes per launch; pt_tune: 2 LDS + 1 scalar dispatches, then 2 scalar)",
-               "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]},
-              open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
+    rec = {"pt_trace_kernel_hbm_bytes_per_launch": int(traffic), "kernel": out.get("pmc_kernel"),
+           "workload": "bench.py --steps 16 --warmup 16 (config 2, 16 passes per launch; pt_tune runs each usable path, then the timed launches use the fastest)",
+           "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]}
+    # what the kernel actually issued (the hierarchy walk skips most of the algorithmic tests):
+    # wave-level VALU instructions per launch and the share of the chip's VALU issue slots they
+    # fill (one wave64 instruction occupies a SIMD's 32 lanes for 2 cycles; GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs)
+    if "SQ_INSTS_VALU" in pm and "GRBM_GUI_ACTIVE" in pm:
+        cycles = pm["GRBM_GUI_ACTIVE"] / 8.0
+        rec["valu_insts_per_launch"] = pm["SQ_INSTS_VALU"]
+        rec["kernel_cycles"] = cycles
+        rec["valu_issue_frac"] = 2.0 * pm["SQ_INSTS_VALU"] / (1024.0 * cycles)
+        for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES"):
+            if k in pm:
+                rec[k.lower()] = pm[k]
+    json.dump(rec, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)

@@ -36,6 +36,9 @@
 #define PT_QUEUE_CHUNK 32u   // work items reserved per global-queue atomic
 #define PT_COOP_MAX_LIVE 16 // tail mode when at most this many lanes of a wave hold a ray
 
+// hip's __ballot takes an int: the bool -> int -> "!= 0" round trip costs two VALU ops per use
+#define pt_ballot(cond) __builtin_amdgcn_ballot_w64(cond)
+
 namespace ptd {
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -298,7 +301,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // traffic) and deals them to its lanes from a wave-uniform local pool.
     for (;;) {
       bool need = !alive && !exhausted;
-      unsigned long long mask = __ballot(need);
+      unsigned long long mask = pt_ballot(need);
       if (mask == 0ull) break;
       if (pool_next == pool_end) { // wave-uniform
         unsigned long long base = 0;
@@ -363,7 +366,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       start_sample();
       new_path = false;
     }
-    unsigned long long live = __ballot(alive);
+    unsigned long long live = pt_ballot(alive);
     if (live == 0ull) break; // every lane is exhausted: the queue is dry
     seg_count += (uint32_t)__popcll(live);
 
@@ -414,7 +417,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // A launch cannot end before its longest (pixel, pass) stream has run its serial course,
     // so waves carrying a long-running item get issue priority: their iterations complete
     // sooner at no cost in total throughput (the SIMD arbitrates by priority, then age).
-    if (__ballot(alive && item_segs > PT_LONG_ITEM_SEGMENTS) != 0ull) __builtin_amdgcn_s_setprio(3);
+    if (pt_ballot(alive && item_segs > PT_LONG_ITEM_SEGMENTS) != 0ull) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
     // The hierarchy walk is latency-bound (per-lane LDS gathers, short dependent loops), so it
     // wants waves, i.e. few VGPRs: the part of the path state that the walk does not touch is
@@ -431,9 +434,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
 #ifdef PT_TIMELINE
     tl_iters++;
-    if (__ballot(exhausted) != 0ull) { if (!tl_dry) tl_dry = __builtin_amdgcn_s_memrealtime(); tl_dry_iters++; }
+    if (pt_ballot(exhausted) != 0ull) { if (!tl_dry) tl_dry = __builtin_amdgcn_s_memrealtime(); tl_dry_iters++; }
 #endif
-    const bool coop = (n_live <= (int)A.coop_max_live) && (__ballot(alive && !fast) == 0ull);
+    const bool coop = (n_live <= (int)A.coop_max_live) && (pt_ballot(alive && !fast) == 0ull);
     if (coop) {
 #ifdef PT_TIMELINE
       if (!tl_coop) tl_coop = __builtin_amdgcn_s_memrealtime();
@@ -514,8 +517,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       //     m = 1.25e-3 (|o - c0|_1 + s0) + 1e-6     >= sqrt(E) + slab rounding
       // (|o-C| <= |o-c0| + |C-c0|, |C-c0| + |r| <= s0; sqrt(18 u) = 1.04e-3, sqrt(7 u) = 6.5e-4;
       // the 20 % on top cover the roundings of o - c0, (o - c0 +- m) / d and of the fused slab
-      // form, each of relative size u; 1e-6 keeps m positive for degenerate scenes) and tested
-      // with a slab test whose comparison carries a relative slack of 1e-6 >= 6u.  The boxes
+      // form, each of relative size u, i.e. < 4u (|o - c0|_1 + s0) in space; 1e-6 keeps m
+      // positive for degenerate scenes) and tested with a plain slab test.  The boxes
       // are stored as binary16 in the frame (x - c0) * k, rounded outward (pt_bvh.hpp), and
       // enter the fused multiply-add directly (v_fma_mix_f32).  Reciprocal directions are
       // clamped to +-1e18: a component that small moves the ray by < 1e-13 over t <= MAX_T, far
@@ -548,7 +551,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       };
       // pops and evaluates queued candidates while more than `keep` are queued (lockstep)
       auto drain_to = [&](uint32_t keep) {
-        while (__ballot(q_cnt > keep) != 0ull) {
+        while (pt_ballot(q_cnt > keep) != 0ull) {
 #ifdef PT_TIMELINE
           tl_p2_iters++;
 #endif
@@ -621,9 +624,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         for (;;) {
           // loop-carried state changes through selects only; the one real branch is the push
           const bool act = (cur < n_nodes) & (l_cnt < 8u);
-          if (__ballot(act) == 0ull) break;
+          if (pt_ballot(act) == 0ull) break;
 #ifdef PT_TIMELINE
-          tl_p3_entries++; tl_ovf_lanes += __popcll(__ballot(act));
+          tl_p3_entries++; tl_ovf_lanes += __popcll(pt_ballot(act));
 #endif
           // idle lanes read too (cur <= n_nodes: the node array carries one spare entry)
           float t1x, t2x, t1y, t2y, t1z, t2z;
@@ -651,7 +654,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           const float tf = __builtin_fminf(
               __builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
               __builtin_fmaxf(t1z, t2z));
-          const bool through = tn <= tf * 1.000001f;
+          // no relative slack on the comparison: the slab arithmetic's rounding, <= 4u (|p|_1 + s0)
+          // in space, is a thousandth of the 20 % the margin carries beyond sqrt(E)
+          const bool through = tn <= tf;
           if (act && through && leaf != 0xffffu) {
             l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
             l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
@@ -662,7 +667,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           const uint32_t nxt = through ? cur + 1u : skip;
           cur = act ? nxt : cur;
         }
-        while (__ballot(l_cnt != 0u) != 0ull) {
+        while (pt_ballot(l_cnt != 0u) != 0ull) {
 #ifdef PT_TIMELINE
           tl_p3_spheres++;
 #endif
@@ -686,7 +691,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             PT_SLOT_PAIR(g2, g3, base + 2u, busy)
           }
         }
-        if (__ballot(cur < n_nodes) == 0ull) break;
+        if (pt_ballot(cur < n_nodes) == 0ull) break;
       }
 #undef PT_SLOT_GROUP
 #undef PT_SLOT_PAIR
@@ -747,7 +752,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 #undef PT_GROUP
 
     // PHASE 2: exact evaluation of the queued candidates, newest (largest index) first
-    while (__ballot(q_cnt != 0u) != 0ull) {
+    while (pt_ballot(q_cnt != 0u) != 0ull) {
 #ifdef PT_TIMELINE
       tl_p2_iters++;
 #endif
@@ -775,7 +780,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // PHASE 3: the shader's loop verbatim for whatever the queue does not cover (rare)
     {
       const bool lit = alive && lit_from < n_spheres;
-      unsigned long long lit_mask = __ballot(lit);
+      unsigned long long lit_mask = pt_ballot(lit);
       if (lit_mask != 0ull) {
         // wave-uniform start: the smallest lit_from of any lane
         uint32_t start = lit ? lit_from : 0xffffffffu;

@@ -208,7 +208,7 @@ def visited_slots(b, o, d, packed=True):
         t2 = fma(np.broadcast_to(hi16[i], o.shape), kk, al)
         tn = np.maximum(np.minimum(t1, t2).max(1), f32(0))
         tf = np.maximum(t1, t2).min(1)
-        through = tn <= f32(tf * f32(1.000001))
+        through = tn <= tf
         if leaf[i] != 0xFFFF:
             seen[act & through, 4 * leaf[i]:4 * leaf[i] + 4] = True
         cur = np.where(act, np.where(through, i + 1, skip[i]), cur)

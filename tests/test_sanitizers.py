@@ -74,6 +74,32 @@ def test_oracle_and_host_code_under_asan_ubsan(tmp_path):
         O.ora_resolve_rgba8(acc.ctypes.data_as(fp), acc.size // 4, 4, 1, px.ctypes.data_as(C.c_void_p))
         assert seg > 0 and np.isfinite(out[:, 3:p.width - 5]).all()
         H.pt_state_destroy(h)
+        # host: the hierarchy builder (binned SAH, outliers, binary16 packing) on awkward scenes
+        from ray_tracer_webgl_amd import scenes
+        vp = C.c_void_p
+        H.pt_build_bvh.argtypes = [C.POINTER(abi.PtSphere), C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
+                                   vp, vp, vp, C.c_size_t, C.POINTER(C.c_float), vp, C.c_size_t]
+        rng = np.random.default_rng(3)
+        cover = scenes.config2(64, 36, 1, 1, 8).spheres
+        same = cover[:200].copy(); same["center"][:] = (1.0, 2.0, 3.0)
+        huge = cover.copy(); huge["center"] *= np.float32(1e12)
+        tiny = cover[:17].copy(); tiny["radius"] = np.float32(1e-30)
+        flat = cover.copy(); flat["center"][:, 1] = 0.0; flat["center"][:, 2] = 0.0
+        built = 0
+        for sph in (cover, same, huge, tiny, flat, cover[:15], cover[:16]):
+            ptr, n, keep = abi.spheres_as_ctypes(sph)
+            cnt = np.zeros(5, np.uint32); mar = np.zeros(4, np.float32)
+            rc = H.pt_build_bvh(ptr, n, None, 0, None, 0, None, 0, mar.ctypes.data, cnt.ctypes.data, None, 0, None, None, 0)
+            if rc != 0:
+                continue
+            nodes = np.zeros(int(cnt[0]) * 8, np.float32); slots = np.zeros(int(cnt[1]) * 4, np.float32)
+            idx = np.zeros(int(cnt[1]), np.uint32); n16 = np.zeros((int(cnt[0]) + 1) * 4, np.uint32)
+            n32 = np.zeros((int(cnt[0]) + 1) * 8, np.float32); k = C.c_float(0)
+            rc = H.pt_build_bvh(ptr, n, nodes.ctypes.data, nodes.size, slots.ctypes.data, slots.size, idx.ctypes.data, idx.size,
+                                mar.ctypes.data, cnt.ctypes.data, n16.ctypes.data, n16.size, C.byref(k), n32.ctypes.data, n32.size)
+            assert rc == 0 and sorted(idx[idx != 0xFFFFFFFF].tolist()) == list(range(n))
+            built += 1
+        assert built >= 5
         print("SANITIZED-OK", int(seg))
     ''') % (ROOT, ora_so, host_so)
     env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",

@@ -8,14 +8,24 @@ from ray_tracer_webgl_amd.tracer import render_scene
 from test_gpu_fuzz import random_scene
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bvh = len(sys.argv) > 3 and sys.argv[3] == "bvh"  # force the hierarchy walk on scenes that get a tree
 bad = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
-    n = int(rng.choice([1, 2, 5, 9, 17, 40, 130, 400]))
+    n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500, 4000] if bvh else [1, 2, 5, 9, 17, 40, 130, 400]))
     width, height = int(rng.integers(9, 200)), int(rng.integers(5, 120))
+    if n >= 400:
+        width, height = min(width, 64), min(height, 40)
     spp, depth, passes = int(rng.integers(1, 9)), int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 5))
     sc = random_scene(rng, n, width, height, spp, depth, passes)
-    path = int(rng.integers(0, 3))
+    path = int(rng.integers(0, 4))
+    if bvh:
+        path = 3
+        if seed % 3 != 1:  # spread the field out so that the tree has something to cull
+            sc.spheres["center"] *= np.float32(rng.choice([2.0, 4.0, 15.0, 100.0]))
+        if seed % 7 == 0:  # and far from the origin: the margin works in the frame of the scene
+            sc.spheres["center"] += np.float32(rng.choice([50.0, 3000.0]))
+            sc.params.camera_origin[0] += float(sc.spheres["center"][0][0]) * 0  # camera stays: distant views
     t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=path)
     ref, seg = oracle.render(sc.spheres, sc.params, passes)
     ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and t.stats().segments == seg
