@@ -575,6 +575,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     A.n_nodes = c->bvh_n_nodes;
     A.n_tree_slots = c->bvh_n_tree_slots;
     A.n_slots = c->bvh_n_slots;
+    A.n_outliers = c->bvh_n_outliers;
     for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
     A.bvh_s0 = c->bvh_s0;
     A.bvh_kinv = c->bvh_kinv;
@@ -767,6 +768,11 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   memset(out, 0, sizeof *out);
 #ifdef PT_TIMELINE
   fprintf(stderr, "TIMELINE iters %llu phase3_entries %llu phase3_spheres %llu phase2_iters %llu overflow_lanes %llu\n", ctr[3], ctr[4], ctr[5], ctr[6], ctr[7]);
+  {
+    double tot = 0; for (int k = 8; k < 15; k++) tot += (double)ctr[k];
+    fprintf(stderr, "TIMELINE wall-time shares: refill+camera %.3f  setup+outliers %.3f  node loops %.3f  leaf loops %.3f  final drain %.3f  shading %.3f  tail mode %.3f\n",
+            ctr[8] / tot, ctr[9] / tot, ctr[10] / tot, ctr[11] / tot, ctr[12] / tot, ctr[13] / tot, ctr[14] / tot);
+  }
 #endif
   out->segments = ctr[PT_CTR_SEGMENTS];
   out->samples = c->samples;

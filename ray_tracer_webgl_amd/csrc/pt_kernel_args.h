@@ -60,7 +60,7 @@ struct PtKernelArgs {
   const float* bvh_nodes32;        // (n_nodes + 1) x 32 B: {lo - c0, skip, hi - c0, leaf}, fp32 (small scenes)
   const float* bvh_slots;          // n_slots x {cx, cy, cz, r*r}: leaves (4 slots each), then the outliers
   const uint32_t* bvh_slot_index;  // n_slots: original sphere index of a slot
-  uint32_t n_nodes, n_tree_slots, n_slots;
+  uint32_t n_nodes, n_tree_slots, n_slots, n_outliers;
   float bvh_c0[3], bvh_s0;         // per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
   uint32_t block_threads;          // blockDim.x of the launch
@@ -69,7 +69,7 @@ struct PtKernelArgs {
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
 };
 
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 8 };
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 16 };
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.

@@ -268,6 +268,13 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   unsigned long long tl_start = __builtin_amdgcn_s_memrealtime(), tl_dry = 0, tl_coop = 0;
   uint32_t tl_iters = 0, tl_coop_iters = 0, tl_dry_iters = 0;
   unsigned long long tl_p3_entries = 0, tl_p3_spheres = 0, tl_p2_iters = 0, tl_ovf_lanes = 0;
+  // wall time per phase of the main loop (100 MHz ticks): [0] refill + camera rays, [1] set-up +
+  // outliers, [2] node loops, [3] leaf loops, [4] final drain, [5] shading, [6] tail mode
+  unsigned long long tl_ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl_mark = __builtin_amdgcn_s_memrealtime();
+#define PT_PHASE(k) { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph[k] += now_ - tl_mark; tl_mark = now_; }
+#else
+#define PT_PHASE(k)
 #endif
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
@@ -368,6 +375,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
     unsigned long long live = pt_ballot(alive);
     if (live == 0ull) break; // every lane is exhausted: the queue is dry
+    PT_PHASE(0)
     seg_count += (uint32_t)__popcll(live);
 
     // ---- hit_world: static/shader.frag:175-196 over the LDS list -------------------------------
@@ -403,6 +411,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // verbatim, in ascending order, from the first sphere the queue does not cover.
     float closest = PT_MAX_T;
     int hit = -1;
+    uint32_t hit_pos = 0xffffffffu; // hierarchy walk: the slot of the closest hit (its sphere index is looked up once, at the end)
     const bool fast = A.scene_regular && (a > 1e-12f) && (a < 1e6f) &&
                       (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
                                        __builtin_fabsf(o.z)) < 1e15f);
@@ -541,12 +550,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         const float sqrtd = __builtin_sqrtf(disc);
         float v = (-half_b - sqrtd) / a;             // :158
         if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; // :159-160
-        const int idx = (int)A.bvh_slot_index[pos];
         // order-free form of the shader's acceptance: smaller root wins, equal roots go to the
-        // later sphere (hit == -1 loses to everything, so v == MAX_T is accepted as in :159)
-        if (!(v < PT_MIN_T) && (v < closest || (v == closest && idx > hit))) {
+        // LATER sphere of the list (no hit yet loses to everything, so v == MAX_T is accepted as
+        // in :159).  Sphere indices are only looked up for the rare exact tie.
+        bool wins = v < closest;
+        if (v == closest)
+          wins = hit_pos == 0xffffffffu || A.bvh_slot_index[pos] > A.bvh_slot_index[hit_pos];
+        if (!(v < PT_MIN_T) && wins) {
           closest = v;
-          hit = idx;
+          hit_pos = pos;
         }
       };
       // pops and evaluates queued candidates while more than `keep` are queued (lockstep)
@@ -574,20 +586,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         q0 = (q0 << 16) | pos;
         q_cnt++;
       };
-#define PT_SLOT_GROUP(C0, C1, C2, C3, BASE, ACTIVE)                                 \
-  {                                                                               \
-    PT_TEST(C0, hb0, cc0, ds0)                                                    \
-    PT_TEST(C1, hb1, cc1, ds1)                                                    \
-    PT_TEST(C2, hb2, cc2, ds2)                                                    \
-    PT_TEST(C3, hb3, cc3, ds3)                                                    \
-    const float dsmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(ds0, ds1), ds2), ds3); \
-    if ((ACTIVE) && dsmax >= 0.0f) { /* padding slots have ds = -inf */           \
-      if (!(ds0 < 0.0f)) note_slot((BASE) + 0u, hb0, cc0);                        \
-      if (!(ds1 < 0.0f)) note_slot((BASE) + 1u, hb1, cc1);                        \
-      if (!(ds2 < 0.0f)) note_slot((BASE) + 2u, hb2, cc2);                        \
-      if (!(ds3 < 0.0f)) note_slot((BASE) + 3u, hb3, cc3);                        \
-    }                                                                             \
-  }
 #define PT_SLOT_PAIR(C0, C1, BASE, ACTIVE)                                          \
   {                                                                               \
     PT_TEST(C0, hb0, cc0, ds0)                                                    \
@@ -598,10 +596,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }                                                                             \
   }
       // the outliers: wave-uniform walk (scalar loads), as the list kernels do for every sphere
-      for (uint32_t i = A.n_tree_slots; i < A.n_slots; i += 4u) {
-        if (i != A.n_tree_slots) drain_to(4u); // a group adds up to four candidates to a queue of eight
-        const f4v e0 = c_slots[i], e1 = c_slots[i + 1u], e2 = c_slots[i + 2u], e3 = c_slots[i + 3u];
-        PT_SLOT_GROUP(e0, e1, e2, e3, i, scan_lane)
+      // (one at a time: there is usually exactly one, the ground)
+      for (uint32_t i = A.n_tree_slots; i < A.n_tree_slots + A.n_outliers; i++) {
+        if (((i - A.n_tree_slots) & 3u) == 0u && i != A.n_tree_slots) drain_to(4u); // room for four more
+        const f4v e0 = c_slots[i];
+        PT_TEST(e0, hb0, cc0, ds0)
+        if (scan_lane && !(ds0 < 0.0f)) note_slot(i, hb0, cc0);
       }
 
       const float px = o.x - A.bvh_c0[0], py = o.y - A.bvh_c0[1], pz = o.z - A.bvh_c0[2];
@@ -620,6 +620,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
       uint32_t cur = scan_lane ? 0u : n_nodes;
+      PT_PHASE(1)
       for (;;) {
         for (;;) {
           // loop-carried state changes through selects only; the one real branch is the push
@@ -667,6 +668,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           const uint32_t nxt = through ? cur + 1u : skip;
           cur = act ? nxt : cur;
         }
+        PT_PHASE(2)
         while (pt_ballot(l_cnt != 0u) != 0ull) {
 #ifdef PT_TIMELINE
           tl_p3_spheres++;
@@ -691,13 +693,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             PT_SLOT_PAIR(g2, g3, base + 2u, busy)
           }
         }
+        PT_PHASE(3)
         if (pt_ballot(cur < n_nodes) == 0ull) break;
       }
-#undef PT_SLOT_GROUP
 #undef PT_SLOT_PAIR
 
       // PHASE 2: exact evaluation of whatever is still queued
       drain_to(0u);
+      if (hit_pos != 0xffffffffu) hit = (int)A.bvh_slot_index[hit_pos];
+      PT_PHASE(4)
     } else {
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
       if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
@@ -815,6 +819,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
     } // !coop
 #undef PT_TEST
+    if (coop) PT_PHASE(6)
 
     if constexpr (BVH) {
       lds_u32* ps = park;
@@ -842,7 +847,13 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
         finished = true;
       } else {
-        float4 g = geom_at((uint32_t)hit);
+        float4 g;
+        if constexpr (BVH) { // the walk's hits come with their slot (same four floats as the list entry)
+          if (hit_pos != 0xffffffffu) g = slot_at(hit_pos);
+          else g = geom_at((uint32_t)hit);
+        } else {
+          g = geom_at((uint32_t)hit);
+        }
         const float4* mp = reinterpret_cast<const float4*>(A.mat + hit);
         float4 m0 = mp[0]; // albedo.xyz, fuzz
         float4 m1 = mp[1]; // refraction_index, type, radius, uuid
@@ -930,6 +941,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
     }
+    PT_PHASE(5)
     sample_count += 0; // (samples are derived on the host: pixels * spp * passes)
   }
 
@@ -939,11 +951,13 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     unsigned long long* t = A.timeline + 8ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     t[0] = tl_start; t[1] = tl_dry; t[2] = tl_coop; t[3] = __builtin_amdgcn_s_memrealtime();
     t[4] = tl_iters; t[5] = tl_dry_iters; t[6] = tl_coop_iters; t[7] = seg_count;
+    for (int k = 0; k < 7; k++) atomicAdd(&A.counters[8 + k], tl_ph[k]);
     atomicAdd(&A.counters[4], tl_p3_entries); atomicAdd(&A.counters[5], tl_p3_spheres); atomicAdd(&A.counters[6], tl_p2_iters); atomicAdd(&A.counters[7], tl_ovf_lanes); atomicAdd(&A.counters[3], (unsigned long long)tl_iters);
   }
 #endif
   (void)sample_count;
 #undef lane
+#undef PT_PHASE
 }
 
 // blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
