@@ -7,7 +7,7 @@ from ray_tracer_webgl_amd import scenes
 from ray_tracer_webgl_amd.tracer import PathTracer
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-sc = scenes.config2(1920, 1080, 64, 16, 50)
+sc = scenes.config5(1920, 1080, 64, 4, 50) if os.environ.get('PT_SCENE') == 'config5' else scenes.config2(1920, 1080, 64, 16, 50)
 pt = PathTracer(1920, 1080)
 pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(16)
 if os.environ.get('PT_GEOM'):
