@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-list-walk"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
 i=0
 for grp in \

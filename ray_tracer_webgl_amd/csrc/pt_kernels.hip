@@ -272,9 +272,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   // outliers, [2] node loops, [3] leaf loops, [4] final drain, [5] shading, [6] tail mode
   unsigned long long tl_ph[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl_mark = __builtin_amdgcn_s_memrealtime();
-#define PT_PHASE(k) { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph[k] += now_ - tl_mark; tl_mark = now_; }
+#define PT_PHASE(k) do { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph[k] += now_ - tl_mark; tl_mark = now_; } while (0)
 #else
-#define PT_PHASE(k)
+#define PT_PHASE(k) do { } while (0)
 #endif
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
@@ -375,7 +375,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
     unsigned long long live = pt_ballot(alive);
     if (live == 0ull) break; // every lane is exhausted: the queue is dry
-    PT_PHASE(0)
+    PT_PHASE(0);
     seg_count += (uint32_t)__popcll(live);
 
     // ---- hit_world: static/shader.frag:175-196 over the LDS list -------------------------------
@@ -620,7 +620,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
       uint32_t cur = scan_lane ? 0u : n_nodes;
-      PT_PHASE(1)
+      PT_PHASE(1);
       for (;;) {
         for (;;) {
           // loop-carried state changes through selects only; the one real branch is the push
@@ -668,7 +668,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           const uint32_t nxt = through ? cur + 1u : skip;
           cur = act ? nxt : cur;
         }
-        PT_PHASE(2)
+        PT_PHASE(2);
         while (pt_ballot(l_cnt != 0u) != 0ull) {
 #ifdef PT_TIMELINE
           tl_p3_spheres++;
@@ -693,7 +693,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             PT_SLOT_PAIR(g2, g3, base + 2u, busy)
           }
         }
-        PT_PHASE(3)
+        PT_PHASE(3);
         if (pt_ballot(cur < n_nodes) == 0ull) break;
       }
 #undef PT_SLOT_PAIR
@@ -701,7 +701,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // PHASE 2: exact evaluation of whatever is still queued
       drain_to(0u);
       if (hit_pos != 0xffffffffu) hit = (int)A.bvh_slot_index[hit_pos];
-      PT_PHASE(4)
+      PT_PHASE(4);
     } else {
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
       if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
@@ -819,7 +819,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
     } // !coop
 #undef PT_TEST
-    if (coop) PT_PHASE(6)
+    if (coop) { PT_PHASE(6); }
 
     if constexpr (BVH) {
       lds_u32* ps = park;
@@ -941,7 +941,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
     }
-    PT_PHASE(5)
+    PT_PHASE(5);
     sample_count += 0; // (samples are derived on the host: pixels * spp * passes)
   }
 
