@@ -230,7 +230,7 @@ int pt_tune(pt_ctx* ctx, uint32_t n_passes);
  * n_tree_slots, n_outliers, depth}; nodes16 = the packed form the kernels read, 4 words per node
  * for n_nodes + 1 nodes {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z as binary16 of (x - c0) * kscale rounded
  * outward, skip | leaf_number << 16}; nodes32 = the fp32 form small scenes use, 8 floats per
- * node for n_nodes + 1 nodes {lo - c0, bits(skip), hi - c0, bits(leaf_number)}.  Array pointers
+ * node for n_nodes + 1 nodes {lo - c0, bits(32 * skip), hi - c0, bits(leaf_number)}.  Array pointers
  * may be NULL (sizes only); capacities are in elements.  Returns PT_ERR_NOT_READY when the scene gets no hierarchy (fewer than 16
  * spheres, non-finite values), PT_ERR_CAPACITY when an array is too small. */
 int pt_build_bvh(const PtSphere* spheres, uint32_t n, float* nodes, size_t node_floats, float* slots,

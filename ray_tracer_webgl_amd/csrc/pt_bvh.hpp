@@ -22,7 +22,7 @@
 //           in depth-first order: the left child of node i is i+1; `skip` is the node that
 //           follows i's subtree (n_nodes ends the walk); leaf = first slot of a leaf (a multiple
 //           of 4) or 0xffffffff for an inner node.  (Host form: tests, pt_build_bvh.)
-//   nodes32 : what the kernel for small scenes reads — {lo - c0, bits(skip), hi - c0,
+//   nodes32 : what the kernel for small scenes reads — {lo - c0, bits(32 * skip), hi - c0,
 //           bits(leaf_number)}, fp32 rounded outward, plus the spare node described below.
 //   nodes16 : what the kernels for larger scenes read — the same nodes packed into 16 bytes: six binary16 box
 //           coordinates {lo.x|lo.y, lo.z|hi.x, hi.y|hi.z} in the frame (x - c0) * kscale
@@ -340,11 +340,11 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Bvh* out) 
         out->nodes32[8 * i + 4 + k] = round_up((double)out->nodes[8 * i + 4 + k] - (double)out->c0[k]);
       }
       const uint32_t leaf = bits(out->nodes[8 * i + 7]);
-      out->nodes32[8 * i + 3] = out->nodes[8 * i + 3];
+      out->nodes32[8 * i + 3] = from_bits(bits(out->nodes[8 * i + 3]) * 32u);  // skip link as a byte offset
       out->nodes32[8 * i + 7] = from_bits(leaf == kInner ? 0xffffu : leaf / kLeafSize);
     }
     for (int k = 0; k < 8; k++) out->nodes32[8 * out->n_nodes + k] = 0.f;
-    out->nodes32[8 * out->n_nodes + 3] = from_bits(out->n_nodes);
+    out->nodes32[8 * out->n_nodes + 3] = from_bits(out->n_nodes * 32u);
     out->nodes32[8 * out->n_nodes + 7] = from_bits(0xffffu);
     // the spare node: an inner node that links to the end of the walk
     out->nodes16[4 * out->n_nodes + 0] = 0; out->nodes16[4 * out->n_nodes + 1] = 0;

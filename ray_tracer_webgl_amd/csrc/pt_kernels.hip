@@ -194,7 +194,13 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   }
   if constexpr (BVH_MODE == 1) { // [2 * (n_nodes + 1) halves of fp32 nodes][n_slots slots]
     const uint32_t n_a = 2u * (A.n_nodes + 1u);
-    for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) s_geom[i] = g_nodes32[i];
+    typedef float4 __attribute__((address_space(3))) lds_f4s;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_f4s*)s_geom;
+    for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) {
+      float4 v = g_nodes32[i];
+      if ((i & 1u) == 0u) v.w = u2f(f2u(v.w) + lds_base); // skip link: byte offset -> LDS address
+      s_geom[i] = v;
+    }
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += blockDim.x) s_geom[n_a + i] = g_slots[i];
     __syncthreads();
   }
@@ -619,21 +625,33 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       const float ahz = -((pz + mrg) * iz), alz = -((pz - mrg) * iz);
       typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
-      uint32_t cur = scan_lane ? 0u : n_nodes;
+      // fp32 nodes: the cursor is the node's LDS address (skip links are stored as byte offsets
+      // and rebased to LDS addresses when the nodes are staged); packed nodes: the node index
+      constexpr uint32_t walk_step = BVH_MODE == 1 ? 32u : 1u;
+      typedef float4 __attribute__((address_space(3))) lds_f4w;
+      const uint32_t walk_base = BVH_MODE == 1 ? (uint32_t)(uintptr_t)(lds_f4w*)s_geom : 0u;
+      const uint32_t walk_end = walk_base + n_nodes * walk_step;
+      uint32_t cur = scan_lane ? walk_base : walk_end;
       PT_PHASE(1);
       for (;;) {
+        // Loop-carried state changes through selects only; the one real branch is the push.  A
+        // lane whose walk is over rests on the spare node behind the tree (it links to itself,
+        // and `through` is masked); the loop pauses for the leaf phase as soon as ANY lane's leaf
+        // queue is full, so no lane ever has to stall on its own.  With fp32 nodes `cur` is
+        // the node's byte offset (skip links are stored scaled): no address arithmetic.
         for (;;) {
-          // loop-carried state changes through selects only; the one real branch is the push
-          const bool act = (cur < n_nodes) & (l_cnt < 8u);
-          if (pt_ballot(act) == 0ull) break;
+          const bool on = cur < walk_end;
+          if (pt_ballot(on) == 0ull) break;
+          if (pt_ballot(l_cnt == 8u) != 0ull) break;
 #ifdef PT_TIMELINE
-          tl_p3_entries++; tl_ovf_lanes += __popcll(pt_ballot(act));
+          tl_p3_entries++; tl_ovf_lanes += __popcll(pt_ballot(on));
 #endif
-          // idle lanes read too (cur <= n_nodes: the node array carries one spare entry)
           float t1x, t2x, t1y, t2y, t1z, t2z;
           uint32_t skip, leaf;
           if constexpr (BVH_MODE == 1) {
-            const float4 na = s_geom[2u * cur], nb = s_geom[2u * cur + 1u]; // lo.xyz skip | hi.xyz leaf
+            typedef const f4v __attribute__((address_space(3))) lds_f4;
+            lds_f4* np = (lds_f4*)(uintptr_t)cur; // `cur` is the node's LDS address itself
+            const f4v na = np[0], nb = np[1];     // lo.xyz skip | hi.xyz leaf
             t1x = fma_(na.x, kx, ahx); t2x = fma_(nb.x, kx, alx);
             t1y = fma_(na.y, ky, ahy); t2y = fma_(nb.y, ky, aly);
             t1z = fma_(na.z, kz, ahz); t2z = fma_(nb.z, kz, alz);
@@ -657,16 +675,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
               __builtin_fmaxf(t1z, t2z));
           // no relative slack on the comparison: the slab arithmetic's rounding, <= 4u (|p|_1 + s0)
           // in space, is a thousandth of the 20 % the margin carries beyond sqrt(E)
-          const bool through = tn <= tf;
-          if (act && through && leaf != 0xffffu) {
+          const bool through = on && tn <= tf;
+          if (through && leaf != 0xffffu) {
             l3 = __builtin_amdgcn_alignbit(l3, l2, 16);
             l2 = __builtin_amdgcn_alignbit(l2, l1, 16);
             l1 = __builtin_amdgcn_alignbit(l1, l0, 16);
             l0 = (l0 << 16) | leaf;
             l_cnt++;
           }
-          const uint32_t nxt = through ? cur + 1u : skip;
-          cur = act ? nxt : cur;
+          cur = through ? cur + walk_step : skip;
         }
         PT_PHASE(2);
         while (pt_ballot(l_cnt != 0u) != 0ull) {
@@ -694,7 +711,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           }
         }
         PT_PHASE(3);
-        if (pt_ballot(cur < n_nodes) == 0ull) break;
+        if (pt_ballot(cur < walk_end) == 0ull) break;
       }
 #undef PT_SLOT_PAIR
 

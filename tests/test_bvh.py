@@ -127,7 +127,7 @@ def test_structure(name):
     # ... and not much bigger: one binary16 step at the rim of the scene
     assert np.all(lo - (lo16[:-1] / k + c0d) <= b["margin"][3] / 1000.0 + 1e-6)
     lo32, hi32, skip32, leaf32 = unpack32(b)
-    assert np.array_equal(skip32, skip16) and np.array_equal(leaf32, leaf16)
+    assert np.array_equal(skip32, 32 * skip16) and np.array_equal(leaf32, leaf16)  # fp32 form: byte offsets
     assert np.all(lo32[:-1].astype(np.float64) + c0d <= lo) and np.all(hi32[:-1].astype(np.float64) + c0d >= hi)
     assert np.all(lo16[:-1] / np.float32(k) <= lo32[:-1]) and np.all(hi16[:-1] / np.float32(k) >= hi32[:-1])
     # the margin's reference data
@@ -187,6 +187,8 @@ def visited_slots(b, o, d, packed=True):
     """the kernel's walk (same formulas, fp32; packed binary16 boxes or the fp32 boxes of small
     scenes): boolean rays x slots, True where a slot is looked at"""
     lo16, hi16, skip, leaf = unpack16(b) if packed else unpack32(b)
+    if not packed:
+        skip = skip // 32
     c0, s0 = b["margin"][:3], b["margin"][3]
     kinv = f32(1.0 / b["kscale"]) if packed else f32(1.0)
     p = f32(o - c0[None, :])
