@@ -686,29 +686,36 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           cur = through ? cur + walk_step : skip;
         }
         PT_PHASE(2);
-        while (pt_ballot(l_cnt != 0u) != 0ull) {
+        // leaf phase: a lane takes a leaf only while its candidate queue (eight entries) has room
+        // for the four a leaf can add; when the only leaves left belong to lanes with fuller
+        // queues, those are drained and the loop resumes.  Pops are branch-free (a variable
+        // shift; an empty queue is all zeros and stays so).
+        for (;;) {
+          for (;;) {
+            const bool busy = (l_cnt != 0u) & (q_cnt <= 4u);
+            if (pt_ballot(busy) == 0ull) break;
 #ifdef PT_TIMELINE
-          tl_p3_spheres++;
+            tl_p3_spheres++;
 #endif
-          drain_to(4u); // a leaf adds up to four candidates to a queue of eight
-          const bool busy = l_cnt != 0u;
-          const uint32_t base = busy ? (l0 & 0xffffu) << 2 : 0u;
-          if (busy) {
-            l0 = __builtin_amdgcn_alignbit(l1, l0, 16);
-            l1 = __builtin_amdgcn_alignbit(l2, l1, 16);
-            l2 = __builtin_amdgcn_alignbit(l3, l2, 16);
-            l3 >>= 16;
-            l_cnt--;
+            const uint32_t base = (l0 & 0xffffu) << 2;
+            const uint32_t sh = busy ? 16u : 0u;
+            l0 = __builtin_amdgcn_alignbit(l1, l0, sh);
+            l1 = __builtin_amdgcn_alignbit(l2, l1, sh);
+            l2 = __builtin_amdgcn_alignbit(l3, l2, sh);
+            l3 >>= sh;
+            l_cnt -= busy ? 1u : 0u;
+            // two slots at a time: the leaf phase is where register pressure peaks
+            {
+              const float4 g0 = slot_at(base), g1 = slot_at(base + 1u);
+              PT_SLOT_PAIR(g0, g1, base, busy)
+            }
+            {
+              const float4 g2 = slot_at(base + 2u), g3 = slot_at(base + 3u);
+              PT_SLOT_PAIR(g2, g3, base + 2u, busy)
+            }
           }
-          // two slots at a time: the leaf phase is where register pressure peaks
-          {
-            const float4 g0 = slot_at(base), g1 = slot_at(base + 1u);
-            PT_SLOT_PAIR(g0, g1, base, busy)
-          }
-          {
-            const float4 g2 = slot_at(base + 2u), g3 = slot_at(base + 3u);
-            PT_SLOT_PAIR(g2, g3, base + 2u, busy)
-          }
+          if (pt_ballot(l_cnt != 0u) == 0ull) break;
+          drain_to(4u);
         }
         PT_PHASE(3);
         if (pt_ballot(cur < walk_end) == 0ull) break;
