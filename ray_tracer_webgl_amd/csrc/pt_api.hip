@@ -588,7 +588,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
     const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
     const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
-    const size_t park1024 = (size_t)PT_PARK_DWORDS * 4 * 1024;
+    const size_t park1024 = (size_t)PT_PARK_STRIDE * 4 * 1024;
     size_t scene = 0;
     if (need_all + park1024 <= lds_max) {
       scene = need_all;
@@ -603,7 +603,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     // staged scene is paid once per workgroup, the parked state and the VGPRs per wave)
     int best_waves = -1;
     for (uint32_t b = 256; b <= 1024; b *= 2) {
-      const size_t l = scene + (size_t)PT_PARK_DWORDS * 4 * b;
+      const size_t l = scene + (size_t)PT_PARK_STRIDE * 4 * b;
       if (l > lds_max) continue;
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) continue;
@@ -615,7 +615,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       if (b == 256u || b == 512u || b == 1024u) bvh_block = b;
     }
     if (!bvh_block) bvh_block = 1024u;
-    lds = scene + (size_t)PT_PARK_DWORDS * 4 * bvh_block;
+    lds = scene + (size_t)PT_PARK_STRIDE * 4 * bvh_block;
   } else {
     // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
     const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;

@@ -76,6 +76,7 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 
 #define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
 #define PT_PARK_DWORDS 14u  // per-lane path state parked in LDS during the hierarchy walk
+#define PT_PARK_STRIDE 15u  // dwords per lane in the parking area (odd: conflict-free columns)
 #define PT_BVH_LDS_BYTES32(n_nodes, n_slots) ((((size_t)(n_nodes) + 1u) * 2u + (size_t)(n_slots)) * 16u)
 #define PT_BVH_LDS_BYTES16(n_nodes) (((size_t)(n_nodes) + 1u) * 16u)
 #define PT_MAX_SPHERES 65528u      // candidate queues hold 16-bit indices; beyond the LDS list the

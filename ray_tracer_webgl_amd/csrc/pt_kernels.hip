@@ -240,11 +240,13 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     else return g_slots[i];
   };
   const_f4v* c_slots = (const_f4v*)A.bvh_slots;
-  // LDS behind the staged scene: PT_PARK_DWORDS columns of blockDim.x dwords (parked path state)
+  // LDS behind the staged scene: PT_PARK_STRIDE dwords per lane for the parked path state.  The
+  // stride is odd, so the 32 lanes of a half-wave hit 32 different banks at any fixed field, and
+  // every field is an immediate offset from the lane's base address.
   typedef volatile uint32_t __attribute__((address_space(3))) lds_u32;
   lds_u32* park = (lds_u32*)reinterpret_cast<uint32_t*>(s_geom) +
                   4u * (BVH_MODE == 1 ? 2u * (A.n_nodes + 1u) + A.n_slots : (BVH_MODE == 2 ? A.n_nodes + 1u : 0u)) +
-                  threadIdx.x;
+                  PT_PARK_STRIDE * threadIdx.x;
 
   // (recomputed where needed rather than kept in a VGPR for the kernel's lifetime)
 #define lane (threadIdx.x & 63u)
@@ -436,16 +438,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     else __builtin_amdgcn_s_setprio(0);
     // The hierarchy walk is latency-bound (per-lane LDS gathers, short dependent loops), so it
     // wants waves, i.e. few VGPRs: the part of the path state that the walk does not touch is
-    // parked in LDS while it runs (14 dwords per lane, one conflict-free column each) and
+    // parked in LDS while it runs (14 dwords per lane, conflict-free, see `park`) and
     // fetched back for shading.  volatile: the values must not be forwarded in registers.
     if constexpr (BVH) {
       lds_u32* ps = park;
-      const uint32_t st = A.block_threads;
-      ps[0 * st] = f2u(sum.x); ps[1 * st] = f2u(sum.y); ps[2 * st] = f2u(sum.z);
-      ps[3 * st] = f2u(col.x); ps[4 * st] = f2u(col.y); ps[5 * st] = f2u(col.z);
-      ps[6 * st] = f2u(seed); ps[7 * st] = f2u(st_s); ps[8 * st] = f2u(st_t);
-      ps[9 * st] = slab_index; ps[10 * st] = item_tile; ps[11 * st] = item_segs;
-      ps[12 * st] = (uint32_t)sample; ps[13 * st] = (uint32_t)depth;
+      ps[0] = f2u(sum.x); ps[1] = f2u(sum.y); ps[2] = f2u(sum.z);
+      ps[3] = f2u(col.x); ps[4] = f2u(col.y); ps[5] = f2u(col.z);
+      ps[6] = f2u(seed); ps[7] = f2u(st_s); ps[8] = f2u(st_t);
+      ps[9] = slab_index; ps[10] = item_tile; ps[11] = item_segs;
+      ps[12] = (uint32_t)sample; ps[13] = (uint32_t)depth;
     }
 #ifdef PT_TIMELINE
     tl_iters++;
@@ -847,12 +848,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
     if constexpr (BVH) {
       lds_u32* ps = park;
-      const uint32_t st = A.block_threads;
-      sum = mk(u2f(ps[0 * st]), u2f(ps[1 * st]), u2f(ps[2 * st]));
-      col = mk(u2f(ps[3 * st]), u2f(ps[4 * st]), u2f(ps[5 * st]));
-      seed = u2f(ps[6 * st]); st_s = u2f(ps[7 * st]); st_t = u2f(ps[8 * st]);
-      slab_index = ps[9 * st]; item_tile = ps[10 * st]; item_segs = ps[11 * st];
-      sample = (int)ps[12 * st]; depth = (int)ps[13 * st];
+      sum = mk(u2f(ps[0]), u2f(ps[1]), u2f(ps[2]));
+      col = mk(u2f(ps[3]), u2f(ps[4]), u2f(ps[5]));
+      seed = u2f(ps[6]); st_s = u2f(ps[7]); st_t = u2f(ps[8]);
+      slab_index = ps[9]; item_tile = ps[10]; item_segs = ps[11];
+      sample = (int)ps[12]; depth = (int)ps[13];
     }
 
     // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
