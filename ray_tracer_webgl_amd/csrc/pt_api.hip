@@ -770,6 +770,8 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   fprintf(stderr, "TIMELINE iters %llu phase3_entries %llu phase3_spheres %llu phase2_iters %llu overflow_lanes %llu\n", ctr[3], ctr[4], ctr[5], ctr[6], ctr[7]);
   {
     double tot = 0; for (int k = 8; k < 15; k++) tot += (double)ctr[k];
+    fprintf(stderr, "TIMELINE items longer than 384: %llu  768: %llu  1536: %llu  2304: %llu  3000: %llu segments (exclusive buckets)\n",
+            ctr[16], ctr[17], ctr[18], ctr[19], ctr[20]);
     fprintf(stderr, "TIMELINE wall-time shares: refill+camera %.3f  setup+outliers %.3f  node loops %.3f  leaf loops %.3f  final drain %.3f  shading %.3f  tail mode %.3f\n",
             ctr[8] / tot, ctr[9] / tot, ctr[10] / tot, ctr[11] / tot, ctr[12] / tot, ctr[13] / tot, ctr[14] / tot);
   }

@@ -959,6 +959,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
           reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
           if (item_tile != 0xffffffffu) atomicMax(&A.tile_cost[item_tile], item_segs);
+#ifdef PT_TIMELINE
+          { // histogram of item lengths (segments): > 384, 768, 1536, 2304, 3000
+            const uint32_t b = (item_segs > 384u) + (item_segs > 768u) + (item_segs > 1536u) + (item_segs > 2304u) + (item_segs > 3000u);
+            if (b) atomicAdd(&A.counters[15 + b], 1ull);
+          }
+#endif
           alive = false;
         } else {
           new_path = true;
