@@ -534,14 +534,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // (|o-C| <= |o-c0| + |C-c0|, |C-c0| + |r| <= s0; sqrt(18 u) = 1.04e-3, sqrt(7 u) = 6.5e-4;
       // the 20 % on top cover the roundings of o - c0, (o - c0 +- m) / d and of the fused slab
       // form, each of relative size u, i.e. < 4u (|o - c0|_1 + s0) in space; 1e-6 keeps m
-      // positive for degenerate scenes) and tested with a plain slab test.  The boxes
-      // are stored as binary16 in the frame (x - c0) * k, rounded outward (pt_bvh.hpp), and
-      // enter the fused multiply-add directly (v_fma_mix_f32).  Reciprocal directions are
+      // positive for degenerate scenes) and tested with a plain slab test.  Boxes live in the
+      // frame x - c0, rounded outward (pt_bvh.hpp): fp32 for scenes whose nodes and slots fit
+      // the LDS together, otherwise packed to binary16 of (x - c0) * k, which enter the fused
+      // multiply-add directly (v_fma_mix_f32, half rate).  Reciprocal directions are
       // clamped to +-1e18: a component that small moves the ray by < 1e-13 over t <= MAX_T, far
       // inside m, and the clamp keeps every product finite (no 0 * inf).  A box that fails the
       // inflated test contains no sphere that could pass; a leaf that survives runs the LITERAL
-      // test on its four slots.  Far-out giants (ground spheres) are not in the tree: they sit
-      // in every lane's leaf queue from the start.
+      // test on its four slots.  Far-out giants (ground spheres) are not in the tree: every ray
+      // tests them first, through scalar loads.
       //
       // Each lane walks the tree on its own (depth-first order with skip links: next = hit ?
       // i + 1 : skip[i]); leaves are queued (8 x 16 bit) and processed in a second lockstep
