@@ -241,7 +241,7 @@ def rays_for(sph, n, seed):
     return f32(o), f32(d)
 
 
-@pytest.mark.parametrize("name", ["config2", "field300", "clumps", "field17_no_giant"])
+@pytest.mark.parametrize("name", ["config2", "field300", "clumps", "field17_no_giant", "config5"])
 def test_walk_reaches_every_sphere_that_can_pass(name):
     sph = SCENES[name]()
     rc, b = build(sph)
@@ -249,8 +249,9 @@ def test_walk_reaches_every_sphere_that_can_pass(name):
     real = b["index"] != INNER
     cs, r2 = b["slots"][:, :3], b["slots"][:, 3]
     total_pass = total_seen = 0
+    n_rays = 4000 if len(sph) < 2000 else 500  # rays x spheres matrices: keep them in memory
     for seed in range(4):
-        o, d = rays_for(sph, 4000, seed)
+        o, d = rays_for(sph, n_rays, seed)
         a = np.einsum("ij,ij->i", d.astype(np.float64), d.astype(np.float64))
         ok = (a > 1e-12) & (a < 1e6)  # the kernel's regular rays; the others take the literal loop
         o, d = o[ok], d[ok]
@@ -265,7 +266,7 @@ def test_walk_reaches_every_sphere_that_can_pass(name):
         assert seen32.sum() <= seen.sum()
         total_pass += int(can_pass.sum())
         total_seen += int(seen.sum())
-    assert total_pass > 1000
+    assert total_pass > 500
     # and the walk does cull: it looks at a small part of the scene
     if len(sph) >= 100:
-        assert total_seen < 0.35 * 4 * 4000 * real.sum()
+        assert total_seen < 0.35 * 4 * n_rays * real.sum()
