@@ -772,6 +772,9 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
     double tot = 0; for (int k = 8; k < 15; k++) tot += (double)ctr[k];
     fprintf(stderr, "TIMELINE items longer than 384: %llu  768: %llu  1536: %llu  2304: %llu  3000: %llu segments (exclusive buckets)\n",
             ctr[16], ctr[17], ctr[18], ctr[19], ctr[20]);
+    fprintf(stderr, "TIMELINE node-loop occupancy by iteration index (x4): ");
+    for (int k = 0; k < 20; k++) fprintf(stderr, "[%d] %.1f lanes x %.3f of steps  ", 4 * k, ctr[44 + k] ? (double)ctr[24 + k] / ctr[44 + k] : 0.0, ctr[3] ? (double)ctr[44 + k] / 4.0 / ctr[3] : 0.0);
+    fprintf(stderr, "\n");
     fprintf(stderr, "TIMELINE wall-time shares: refill+camera %.3f  setup+outliers %.3f  node loops %.3f  leaf loops %.3f  final drain %.3f  shading %.3f  tail mode %.3f\n",
             ctr[8] / tot, ctr[9] / tot, ctr[10] / tot, ctr[11] / tot, ctr[12] / tot, ctr[13] / tot, ctr[14] / tot);
   }

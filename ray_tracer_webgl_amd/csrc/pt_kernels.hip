@@ -279,6 +279,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   // wall time per phase of the main loop (100 MHz ticks): [0] refill + camera rays, [1] set-up +
   // outliers, [2] node loops, [3] leaf loops, [4] final drain, [5] shading, [6] tail mode
   unsigned long long tl_ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl_act[20] = {0}, tl_cnt[20] = {0};
+  uint32_t tl_step_iter = 0;
   unsigned long long tl_mark = __builtin_amdgcn_s_memrealtime();
 #define PT_PHASE(k) do { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph[k] += now_ - tl_mark; tl_mark = now_; } while (0)
 #else
@@ -634,6 +636,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       const uint32_t walk_base = BVH_MODE == 1 ? (uint32_t)(uintptr_t)(lds_f4w*)s_geom : 0u;
       const uint32_t walk_end = walk_base + n_nodes * walk_step;
       uint32_t cur = scan_lane ? walk_base : walk_end;
+#ifdef PT_TIMELINE
+      tl_step_iter = 0;
+#endif
       PT_PHASE(1);
       for (;;) {
         // Loop-carried state changes through selects only; the one real branch is the push.  A
@@ -647,6 +652,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           if (pt_ballot(l_cnt == 8u) != 0ull) break;
 #ifdef PT_TIMELINE
           tl_p3_entries++; tl_ovf_lanes += __popcll(pt_ballot(on));
+          { // active lanes by node-iteration index of this wave step (buckets of 4 iterations)
+            const uint32_t bk = tl_step_iter < 76u ? tl_step_iter >> 2 : 19u;
+            tl_act[bk] += __popcll(pt_ballot(on)); tl_cnt[bk]++;
+            tl_step_iter++;
+          }
 #endif
           float t1x, t2x, t1y, t2y, t1z, t2z;
           uint32_t skip, leaf;
@@ -983,6 +993,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     t[0] = tl_start; t[1] = tl_dry; t[2] = tl_coop; t[3] = __builtin_amdgcn_s_memrealtime();
     t[4] = tl_iters; t[5] = tl_dry_iters; t[6] = tl_coop_iters; t[7] = seg_count;
     for (int k = 0; k < 7; k++) atomicAdd(&A.counters[8 + k], tl_ph[k]);
+    for (int k = 0; k < 20; k++) { atomicAdd(&A.counters[24 + k], tl_act[k]); atomicAdd(&A.counters[44 + k], tl_cnt[k]); }
     atomicAdd(&A.counters[4], tl_p3_entries); atomicAdd(&A.counters[5], tl_p3_spheres); atomicAdd(&A.counters[6], tl_p2_iters); atomicAdd(&A.counters[7], tl_ovf_lanes); atomicAdd(&A.counters[3], (unsigned long long)tl_iters);
   }
 #endif
