@@ -221,7 +221,9 @@ int pt_get_stats(pt_ctx* ctx, PtStats* out);
 int pt_set_option(pt_ctx* ctx, int key, int value);
 /* Settles PT_GEOM_AUTO now instead of lazily: renders n_passes passes with the current scene
  * and uniforms once cold and once per usable path, keeps the fastest path, then clears the
- * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes. */
+ * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes.
+ * Call it before capturing pt_render* into a hipGraph: a captured launch keeps the path it was
+ * captured with (no measuring happens while a stream is capturing). */
 int pt_tune(pt_ctx* ctx, uint32_t n_passes);
 /* The hierarchy pt_set_spheres builds for PT_GEOM_BVH, on the host (no device needed; tests
  * check its invariants): nodes = 8 floats each {lo.xyz, bits(skip), hi.xyz, bits(first slot of
