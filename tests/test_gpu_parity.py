@@ -485,6 +485,33 @@ def test_render_is_hip_graph_capturable(ora):
     t.close()
 
 
+def test_hierarchy_walk_is_hip_graph_capturable(ora):
+    """The same with the cover scene and the hierarchy walk forced: the captured launch carries
+    the hierarchy kernel (dynamic LDS, occupancy-driven workgroup size) and replays bit-exactly."""
+    import torch
+
+    sc = scenes.config2(96, 54, 2, 2, 50)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t = PathTracer(96, 54, use_torch=True)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.set_geometry_path(abi.PT_GEOM_BVH)
+        t.reserve_passes(2)
+        t.render_passes(2)
+        torch.cuda.current_stream().synchronize()
+        t.reset()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            t.render_passes(2)
+    g.replay()
+    torch.cuda.synchronize()
+    ref, _ = ora.render(sc.spheres, sc.params, 2)
+    assert_bit_equal(t.accum_tensor.cpu().numpy()[..., :3], ref[..., :3], "hierarchy graph replay")
+    assert t.stats().geometry_path == abi.PT_GEOM_BVH
+    t.close()
+
+
 def test_sphere_list_beyond_lds_capacity(ora):
     """n > 10 232 spheres do not fit the 160 KiB LDS: the scalar-load walk of the padded
     global copy (pt_trace_kernel_scalar) is used instead.  Window-checked against the oracle."""
