@@ -7,6 +7,7 @@ import argparse
 import time
 
 from . import image_io, scenes
+from . import abi
 from .tracer import render_scene
 
 
@@ -19,6 +20,8 @@ def main(argv=None):
     ap.add_argument("--passes", type=int)
     ap.add_argument("--max-depth", type=int)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--geometry", default="auto", choices=["auto", "lds", "scalar", "bvh"],
+                    help="how the kernel looks at the sphere list (same image bits on every path)")
     ap.add_argument("--out", default="render.png")
     ap.add_argument("--checkpoint", help="also save the fp32 accumulation buffer (.npz)")
     args = ap.parse_args(argv)
@@ -39,7 +42,8 @@ def main(argv=None):
     if args.passes:
         sc.n_passes = args.passes
     t0 = time.perf_counter()
-    pt, acc = render_scene(sc, device=args.device, passes_per_launch=min(sc.n_passes, 16))
+    geom = {"auto": abi.PT_GEOM_AUTO, "lds": abi.PT_GEOM_LDS, "scalar": abi.PT_GEOM_SCALAR, "bvh": abi.PT_GEOM_BVH}[args.geometry]
+    pt, acc = render_scene(sc, device=args.device, passes_per_launch=min(sc.n_passes, 16), geometry_path=geom)
     dt = time.perf_counter() - t0
     st = pt.stats()
     frame = pt.resolve(gamma=True)
