@@ -64,6 +64,7 @@ struct PtKernelArgs {
   float bvh_c0[3], bvh_s0;         // per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
   uint32_t block_threads;          // blockDim.x of the launch
+  uint32_t queue_chunk;            // work items a wave reserves per global-queue atomic
   float fw, fh;                    // float(width), float(height)
   PtDiv div_per_tile, div_tiles_x, div_band_rows;  // by 64 * n_passes, tiles_x, band_rows
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray

@@ -33,7 +33,6 @@
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
 #define PT_LONG_ITEM_SEGMENTS 384u // ~2x the mean item of config 2; see the priority note below
-#define PT_QUEUE_CHUNK 32u   // work items reserved per global-queue atomic
 #define PT_COOP_MAX_LIVE 16 // tail mode when at most this many lanes of a wave hold a ray
 
 // hip's __ballot takes an int: the bool -> int -> "!= 0" round trip costs two VALU ops per use
@@ -313,7 +312,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
   for (;;) {
     // ---- refill: lanes without a ray pull work items ---------------------------------------------
-    // The wave reserves PT_QUEUE_CHUNK consecutive items from the global queue with ONE atomic
+    // The wave reserves A.queue_chunk consecutive items from the global queue with ONE atomic
     // (a memory-side atomic moves 64 B, so per-item atomics would dominate the kernel's HBM
     // traffic) and deals them to its lanes from a wave-uniform local pool.
     for (;;) {
@@ -322,14 +321,14 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       if (mask == 0ull) break;
       if (pool_next == pool_end) { // wave-uniform
         unsigned long long base = 0;
-        if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)PT_QUEUE_CHUNK);
+        if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
         base = __shfl(base, 0);
         if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
           if (need) exhausted = true;
           continue;
         }
         pool_next = (uint32_t)base;
-        unsigned long long end = base + PT_QUEUE_CHUNK;
+        unsigned long long end = base + A.queue_chunk;
         pool_end = end < (unsigned long long)A.n_items ? (uint32_t)end : A.n_items;
       }
       const uint32_t avail = pool_end - pool_next;
