@@ -47,6 +47,8 @@ extern "C" {
     pub fn pt_blend_rgba8(ctx: *mut PtCtx, prev: *const u8, out: *mut u8) -> c_int;
     pub fn pt_accum_ptr(ctx: *mut PtCtx, dev_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
     pub fn pt_bind_accum(ctx: *mut PtCtx, dev_ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn pt_read_accum(ctx: *mut PtCtx, dst: *mut f32, bytes: usize) -> c_int;
+    pub fn pt_load_accum(ctx: *mut PtCtx, src: *const f32, bytes: usize) -> c_int;
     pub fn pt_set_stream(ctx: *mut PtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn pt_last_error(ctx: *mut PtCtx) -> *const c_char;
     pub fn pt_abi_version() -> c_int;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 /* ---- error codes (returned by every int function; 0 = success) ------------------------------ */
 enum {
@@ -199,12 +199,22 @@ int pt_synchronize(pt_ctx* ctx);
 /* ---- read-out: replaces the canvas read (src/dom.rs:126-143) -----------------------------------
  * Writes local_rows*width RGBA fp32 texels (row 0 = lowest owned row): rgb = accum / total_spp,
  * then sqrt when gamma != 0 (static/shader.frag:376-380); a = 1.  `out` may be a host or a
- * device pointer.  Synchronises the stream. */
+ * device pointer.  Synchronises the stream.  The divisor is read per pixel from the device-side
+ * sample count (the buffer's .a), so it is also right after hipGraph replays of a captured
+ * pt_render_passes, which the host-side counters cannot see. */
 int pt_resolve(pt_ctx* ctx, float* rgba_out, int gamma);
 /* Same, clamped and quantised to RGBA8 like the reference framebuffer (src/webgl.rs:109-119). */
 int pt_resolve_rgba8(pt_ctx* ctx, uint8_t* rgba_out, int gamma);
 /* Raw accumulation buffer (local_rows*width float4: r,g,b sums, a = spp): device pointer. */
 int pt_accum_ptr(pt_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* Checkpoint / resume (the reference's accumulation state is its ping-pong textures +
+ * render_count, src/state.rs:443-450): copy the accumulation buffer out / back in.  The sample
+ * count travels inside the buffer (the .a of every pixel), so rendering k passes, pt_read_accum,
+ * a new context with the same scene / uniforms / row partition, pt_load_accum and k more passes
+ * give the bits of 2k uninterrupted passes.  `dst` / `src`: host or device pointers to
+ * local_rows*width*16 bytes.  Both synchronise the stream. */
+int pt_read_accum(pt_ctx* ctx, float* dst, size_t bytes);
+int pt_load_accum(pt_ctx* ctx, const float* src, size_t bytes);
 /* Render into caller-owned device memory (e.g. a torch tensor) instead; NULL restores. */
 int pt_bind_accum(pt_ctx* ctx, void* dev_ptr, size_t bytes);
 /* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */

@@ -32,6 +32,8 @@ SIGNATURES = {
     "pt_resolve_rgba8": (C.c_int, [_ctx, _vp, C.c_int]),
     "pt_accum_ptr": (C.c_int, [_ctx, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "pt_bind_accum": (C.c_int, [_ctx, _vp, C.c_size_t]),
+    "pt_read_accum": (C.c_int, [_ctx, _vp, C.c_size_t]),
+    "pt_load_accum": (C.c_int, [_ctx, _vp, C.c_size_t]),
     "pt_set_stream": (C.c_int, [_ctx, _vp]),
     "pt_blend_rgba8": (C.c_int, [_ctx, _vp, _vp]),
     "pt_get_stats": (C.c_int, [_ctx, C.POINTER(abi.PtStats)]),

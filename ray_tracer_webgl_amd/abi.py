@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-PT_ABI_VERSION = 2
+PT_ABI_VERSION = 3
 
 PT_OK = 0
 PT_ERR_INVALID = -1

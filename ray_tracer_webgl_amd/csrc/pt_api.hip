@@ -46,7 +46,8 @@ struct pt_ctx {
   float4* accum = nullptr; // own_accum or caller-bound
   size_t accum_pixels = 0;
   bool accum_bound = false;
-  uint32_t total_spp = 0;
+  uint32_t total_spp = 0;   // enqueued directly (not through graph replays)
+  bool captured = false;    // some launch was captured into a hipGraph: only the device knows the spp
   // per-pass slabs
   float4* d_slab = nullptr;
   size_t slab_pixels = 0; // capacity in pixels (passes * local pixels)
@@ -409,18 +410,23 @@ PT_API int pt_set_params(pt_ctx* c, const PtParams* p) {
   };
   bool repartition = rows != c->local_rows;
   for (uint32_t k = 0; k < 3; k++) repartition |= eff(*p, k) != eff(c->params, k);
-  c->params = *p;
-  c->have_params = true;
+  // validate first, commit afterwards: a refused call leaves the context as it was
+  if (repartition && c->accum_bound && (size_t)rows * c->width > c->accum_pixels)
+    return fail(c, PT_ERR_CAPACITY, "pt_set_params: bound accumulation buffer too small for %u rows", rows);
   if (repartition) {
+    const uint32_t old_rows = c->local_rows;
     c->local_rows = rows;
-    if (c->accum_bound && (size_t)rows * c->width > c->accum_pixels)
-      return fail(c, PT_ERR_CAPACITY, "pt_set_params: bound accumulation buffer too small");
     int rc = ensure_buffers(c);
-    if (rc != PT_OK) return rc;
+    if (rc != PT_OK) { // allocation failed: keep the previous partition renderable
+      c->local_rows = old_rows;
+      return rc;
+    }
     // a different set of rows: the accumulated image no longer applies
     PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
     c->total_spp = 0;
   }
+  c->params = *p;
+  c->have_params = true;
   return PT_OK;
 }
 
@@ -460,6 +466,7 @@ PT_API int pt_reset_accum(pt_ctx* c) {
   c->kernel_ms = 0.0;
   c->launches = 0;
   c->total_spp = 0;
+  c->captured = false;
   c->samples = 0;
   return PT_OK;
 }
@@ -489,6 +496,36 @@ PT_API int pt_accum_ptr(pt_ctx* c, void** dev_ptr, size_t* bytes) {
   if (!c || !dev_ptr) return PT_ERR_INVALID;
   *dev_ptr = c->accum;
   if (bytes) *bytes = (size_t)c->local_rows * c->width * sizeof(float4);
+  return PT_OK;
+}
+
+// Checkpoint / resume of the accumulation state (the reference's accumulation state is its
+// ping-pong textures + render_count, src/state.rs:443-450; here: local_rows*width float4 of
+// {sum r, sum g, sum b, spp}).  `dst` / `src` may be host or device pointers.
+PT_API int pt_read_accum(pt_ctx* c, float* dst, size_t bytes) {
+  if (!c || !dst) return fail(c, PT_ERR_INVALID, "pt_read_accum: NULL argument");
+  const size_t need = (size_t)c->local_rows * c->width * sizeof(float4);
+  if (bytes < need) return fail(c, PT_ERR_CAPACITY, "pt_read_accum: %zu bytes < %zu needed", bytes, need);
+  PT_HIP(c, hipSetDevice(c->device));
+  if (need) PT_HIP(c, hipMemcpyAsync(dst, c->accum, need, hipMemcpyDefault, c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+PT_API int pt_load_accum(pt_ctx* c, const float* src, size_t bytes) {
+  if (!c || !src) return fail(c, PT_ERR_INVALID, "pt_load_accum: NULL argument");
+  const size_t need = (size_t)c->local_rows * c->width * sizeof(float4);
+  if (bytes != need)
+    return fail(c, PT_ERR_INVALID, "pt_load_accum: %zu bytes, the current row partition holds %zu", bytes, need);
+  PT_HIP(c, hipSetDevice(c->device));
+  if (need) PT_HIP(c, hipMemcpyAsync(c->accum, src, need, hipMemcpyDefault, c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  // the spp count travels in the buffer (the .w of every pixel); mirror it on the host
+  float4 px0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (need) PT_HIP(c, hipMemcpy(&px0, c->accum, sizeof px0, hipMemcpyDeviceToHost));
+  if (!(px0.w >= 0.0f) || px0.w >= 16777216.0f)
+    return fail(c, PT_ERR_INVALID, "pt_load_accum: sample count %g in the buffer is not a count", (double)px0.w);
+  c->total_spp = (uint32_t)px0.w;
   return PT_OK;
 }
 
@@ -610,10 +647,12 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       const int waves = n * (int)(b / 64);
       if (waves > best_waves) { best_waves = waves; bvh_block = b; }
     }
-    if (const char* e = getenv("PT_BVH_BLOCK")) { // dev knob
+#ifdef PT_DEV_KNOBS // A/B builds only (tools/ab_*.sh); the product reads no environment
+    if (const char* e = getenv("PT_BVH_BLOCK")) {
       uint32_t b = (uint32_t)atoi(e);
       if (b == 256u || b == 512u || b == 1024u) bvh_block = b;
     }
+#endif
     if (!bvh_block) bvh_block = 1024u;
     lds = scene + (size_t)PT_PARK_STRIDE * 4 * bvh_block;
   } else {
@@ -638,10 +677,12 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   {
     unsigned long long lanes = (unsigned long long)c->num_cus * (unsigned)per_cu * block;
     A.queue_chunk = items >= 64ull * lanes ? 128u : (items >= 16ull * lanes ? 64u : 32u);
-    if (const char* e = getenv("PT_QUEUE_CHUNK")) { // dev knob
+#ifdef PT_DEV_KNOBS
+    if (const char* e = getenv("PT_QUEUE_CHUNK")) {
       uint32_t v = (uint32_t)atoi(e);
       if (v >= 1u && v <= 4096u) A.queue_chunk = v;
     }
+#endif
   }
   unsigned long long want = (items + block - 1) / block;
   unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
@@ -705,9 +746,16 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
                      c->accum, c->d_slab, n_pix, n_passes);
   PT_HIP(c, hipGetLastError());
 
-  if (!capturing) c->launches++;
-  c->total_spp += n_passes * (uint32_t)p.samples_per_pixel;
-  c->samples += (uint64_t)n_pix * n_passes * (uint64_t)p.samples_per_pixel;
+  // Host-side tallies describe work enqueued directly.  A captured launch runs as often as its
+  // graph is replayed, which the host cannot see: read-out takes its divisor from the device
+  // (accum.w, see pixel_scale), and pt_get_stats reads the accumulated spp back from there.
+  if (capturing) {
+    c->captured = true;
+  } else {
+    c->launches++;
+    c->total_spp += n_passes * (uint32_t)p.samples_per_pixel;
+    c->samples += (uint64_t)n_pix * n_passes * (uint64_t)p.samples_per_pixel;
+  }
   return PT_OK;
 }
 
@@ -733,20 +781,20 @@ PT_API int pt_synchronize(pt_ctx* c) {
 
 static int resolve_common(pt_ctx* c, void* out, int gamma, int mode, const uint8_t* prev) {
   if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_resolve: NULL argument");
-  if (c->total_spp == 0) return fail(c, PT_ERR_NOT_READY, "pt_resolve: nothing rendered yet");
+  if (c->total_spp == 0 && !c->captured) return fail(c, PT_ERR_NOT_READY, "pt_resolve: nothing rendered yet");
   PT_HIP(c, hipSetDevice(c->device));
   uint32_t n_pix = c->local_rows * c->width;
   if (n_pix == 0) return PT_OK;
-  float scale = 1.0f / (float)c->total_spp; // static/shader.frag:376
+  // the 1/spp of static/shader.frag:376 is taken per pixel from accum.w on the device
   uint32_t grid = grid_for(n_pix, 256, 2048);
   size_t bytes;
   if (mode == 0) {
     hipLaunchKernelGGL(pt_resolve_kernel, dim3(grid), dim3(256), 0, c->stream, c->accum, c->d_resolve,
-                       n_pix, scale, gamma);
+                       n_pix, gamma);
     bytes = (size_t)n_pix * sizeof(float4);
   } else if (mode == 1) {
     hipLaunchKernelGGL(pt_resolve_rgba8_kernel, dim3(grid), dim3(256), 0, c->stream, c->accum,
-                       reinterpret_cast<uint32_t*>(c->d_resolve), n_pix, scale, gamma);
+                       reinterpret_cast<uint32_t*>(c->d_resolve), n_pix, gamma);
     bytes = (size_t)n_pix * 4;
   } else {
     // stage prev into the upper half of the resolve buffer (16 B/pixel holds 4 B in + 4 B out)
@@ -754,7 +802,7 @@ static int resolve_common(pt_ctx* c, void* out, int gamma, int mode, const uint8
     uint32_t* d_prev = d_out + n_pix;
     PT_HIP(c, hipMemcpyAsync(d_prev, prev, (size_t)n_pix * 4, hipMemcpyDefault, c->stream));
     hipLaunchKernelGGL(pt_blend_rgba8_kernel, dim3(grid), dim3(256), 0, c->stream, c->accum, d_prev, d_out,
-                       n_pix, scale, c->params.render_count, c->params.should_average,
+                       n_pix, c->params.render_count, c->params.should_average,
                        c->params.last_frame_weight);
     bytes = (size_t)n_pix * 4;
   }
@@ -799,6 +847,11 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   out->render_kernel_ms = c->kernel_ms;
   out->render_launches = c->launches;
   out->total_spp = c->total_spp;
+  if (c->accum && c->local_rows) { // what the device has really accumulated (graph replays included)
+    float4 px0;
+    PT_HIP(c, hipMemcpy(&px0, c->accum, sizeof px0, hipMemcpyDeviceToHost));
+    if (px0.w >= 0.0f && px0.w < 4294967040.0f) out->total_spp = (uint32_t)px0.w;
+  }
   out->n_spheres = c->n_spheres;
   try_finish_tuning(c);
   out->local_rows = c->local_rows;

@@ -269,7 +269,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   float a = 0.f; // dot(d,d), hoisted out of the sphere loop (static/shader.frag:147)
   V3 col = mk(1, 1, 1), sum = mk(0, 0, 0);
 
-  uint32_t seg_count = 0, sample_count = 0; // wave-uniform tallies
+  uint32_t seg_count = 0; // wave-uniform tally (samples are derived on the host: pixels * spp * passes)
   uint32_t pool_next = 0, pool_end = 0;     // wave-uniform: this wave's reserved queue items
 #ifdef PT_TIMELINE
   unsigned long long tl_start = __builtin_amdgcn_s_memrealtime(), tl_dry = 0, tl_coop = 0;
@@ -337,43 +337,39 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       const uint32_t pool_base = pool_next;
       pool_next += cnt < avail ? cnt : avail;
       if (need && rank < avail) {
-        unsigned long long item64 = (unsigned long long)pool_base + rank;
-        if (false) {
-        } else {
-          uint32_t item = (uint32_t)item64;
-          uint32_t per_tile = 64u * A.n_passes;
-          uint32_t tile_pos = div_(item, A.div_per_tile);
-          uint32_t rem = item - tile_pos * per_tile;
-          uint32_t tile = A.tile_order[tile_pos]; // heaviest tiles are dealt first
-          uint32_t pass = rem >> 6, l = rem & 63u;
-          uint32_t ty = div_(tile, A.div_tiles_x), tx = tile - ty * A.tiles_x;
-          uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
-          if (px < A.width && ly < A.local_rows) {
-            uint32_t y = ly;
-            if (A.band_count > 1u) {
-              uint32_t b = div_(ly, A.div_band_rows), r = ly - b * A.band_rows;
-              y = (b * A.band_count + A.band_index) * A.band_rows + r;
-            }
-            // static/shader.vert:8 + rasteriser: v_position at the pixel centre
-            float vx = (float)(2u * px + 1u) / fw - 1.0f;
-            float vy = (float)(2u * y + 1u) / fh - 1.0f;
-            float u_time = A.time0 + (float)pass;
-            // init_global_seed, static/shader.frag:354-357
-            seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
-            st_s = (vx + 1.0f) * 0.5f; // :410
-            st_t = (vy + 1.0f) * 0.5f;
-            slab_index = (pass * A.local_rows + ly) * A.width + px;
-            // only the launch's first pass reports its cost (atomicMax per pixel: the tile's
-            // heaviest item): plenty for ordering tiles, and a memory-side atomic moves 64 B
-            item_tile = pass == 0u ? tile : 0xffffffffu;
-            item_segs = 0;
-            sum = mk(0.f, 0.f, 0.f);
-            sample = 0;
-            new_path = true;
-            alive = true;
+        uint32_t item = pool_base + rank;
+        uint32_t per_tile = 64u * A.n_passes;
+        uint32_t tile_pos = div_(item, A.div_per_tile);
+        uint32_t rem = item - tile_pos * per_tile;
+        uint32_t tile = A.tile_order[tile_pos]; // heaviest tiles are dealt first
+        uint32_t pass = rem >> 6, l = rem & 63u;
+        uint32_t ty = div_(tile, A.div_tiles_x), tx = tile - ty * A.tiles_x;
+        uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
+        if (px < A.width && ly < A.local_rows) {
+          uint32_t y = ly;
+          if (A.band_count > 1u) {
+            uint32_t b = div_(ly, A.div_band_rows), r = ly - b * A.band_rows;
+            y = (b * A.band_count + A.band_index) * A.band_rows + r;
           }
-          // an item that falls outside the image (edge tile) is simply dropped
+          // static/shader.vert:8 + rasteriser: v_position at the pixel centre
+          float vx = (float)(2u * px + 1u) / fw - 1.0f;
+          float vy = (float)(2u * y + 1u) / fh - 1.0f;
+          float u_time = A.time0 + (float)pass;
+          // init_global_seed, static/shader.frag:354-357
+          seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
+          st_s = (vx + 1.0f) * 0.5f; // :410
+          st_t = (vy + 1.0f) * 0.5f;
+          slab_index = (pass * A.local_rows + ly) * A.width + px;
+          // only the launch's first pass reports its cost (atomicMax per pixel: the tile's
+          // heaviest item): plenty for ordering tiles, and a memory-side atomic moves 64 B
+          item_tile = pass == 0u ? tile : 0xffffffffu;
+          item_segs = 0;
+          sum = mk(0.f, 0.f, 0.f);
+          sample = 0;
+          new_path = true;
+          alive = true;
         }
+        // an item that falls outside the image (edge tile) is simply dropped
       }
     }
     // one copy of the camera-ray code per step serves both kinds of lanes: those that just
@@ -982,7 +978,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       }
     }
     PT_PHASE(5);
-    sample_count += 0; // (samples are derived on the host: pixels * spp * passes)
   }
 
   if (lane == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
@@ -996,7 +991,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     atomicAdd(&A.counters[4], tl_p3_entries); atomicAdd(&A.counters[5], tl_p3_spheres); atomicAdd(&A.counters[6], tl_p2_iters); atomicAdd(&A.counters[7], tl_ovf_lanes); atomicAdd(&A.counters[3], (unsigned long long)tl_iters);
   }
 #endif
-  (void)sample_count;
 #undef lane
 #undef PT_PHASE
 }
@@ -1115,13 +1109,19 @@ __device__ __forceinline__ uint32_t unorm8(float v) {
   return (uint32_t)(v * 255.0f + 0.5f);
 }
 
-// read-out, static/shader.frag:376-380 on the accumulated sum
+// read-out, static/shader.frag:376-380 on the accumulated sum.  The divisor is the pixel's own
+// sample count: accum.w carries the sum of float(spp) over the passes folded so far (an exact
+// integer below 2^24), so the scale is the same fp32 value as 1/float(total spp) and it stays
+// right when a captured launch is replayed by a hipGraph behind the host's back.  A pixel that
+// has received nothing reads as 0.
+__device__ __forceinline__ float pixel_scale(float w) { return w > 0.0f ? 1.0f / w : 0.0f; }
+
 extern "C" __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* accum, float4* out,
-                                                                    uint32_t n_pix, float scale,
-                                                                    int gamma) {
+                                                                    uint32_t n_pix, int gamma) {
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
     float4 v = accum[i];
+    const float scale = pixel_scale(v.w);
     float r = v.x * scale, g = v.y * scale, b = v.z * scale;
     if (gamma) { r = __builtin_sqrtf(r); g = __builtin_sqrtf(g); b = __builtin_sqrtf(b); }
     out[i] = make_float4(r, g, b, 1.0f);
@@ -1130,10 +1130,11 @@ extern "C" __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4
 
 extern "C" __global__ __launch_bounds__(256) void pt_resolve_rgba8_kernel(const float4* accum,
                                                                           uint32_t* out, uint32_t n_pix,
-                                                                          float scale, int gamma) {
+                                                                          int gamma) {
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
     float4 v = accum[i];
+    const float scale = pixel_scale(v.w);
     float r = v.x * scale, g = v.y * scale, b = v.z * scale;
     if (gamma) { r = __builtin_sqrtf(r); g = __builtin_sqrtf(g); b = __builtin_sqrtf(b); }
     out[i] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (255u << 24);
@@ -1142,12 +1143,13 @@ extern "C" __global__ __launch_bounds__(256) void pt_resolve_rgba8_kernel(const 
 
 // temporal running mean of the reference, static/shader.frag:387-404 (RGBA8 ping-pong textures)
 extern "C" __global__ __launch_bounds__(256) void pt_blend_rgba8_kernel(
-    const float4* accum, const uint32_t* prev, uint32_t* out, uint32_t n_pix, float scale,
+    const float4* accum, const uint32_t* prev, uint32_t* out, uint32_t n_pix,
     int render_count, int should_average, float last_frame_weight) {
   uint32_t stride = gridDim.x * blockDim.x;
   float rc = (float)render_count;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
     float4 v = accum[i];
+    const float scale = pixel_scale(v.w);
     float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale),
                    __builtin_sqrtf(v.z * scale)};
     uint32_t pv = prev[i];

@@ -148,16 +148,19 @@ class PathTracer:
         if self.accum_tensor is not None:
             self._torch.cuda.current_stream(self.device).synchronize()
             return self.accum_tensor[: self.local_rows].cpu().numpy()
-        ptr = C.c_void_p()
-        nbytes = C.c_size_t()
-        self._check(self.lib.pt_accum_ptr(self._ctx, C.byref(ptr), C.byref(nbytes)))
         out = np.empty((self.local_rows, self.width, 4), dtype=np.float32)
         if out.size:
-            hip = _hip()
-            rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(out.nbytes), 2)
-            if rc != 0:
-                raise PtError(abi.PT_ERR_HIP, "hipMemcpy D2H failed: %d" % rc)
+            self._check(self.lib.pt_read_accum(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
+
+    def load_accum(self, accum):
+        """Resume from a checkpoint: `accum` is what accum() returned earlier (rgb sums, a = spp)
+        for the same image size and row partition (image_io.load_accum reads one from disk)."""
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        if a.shape != (self.local_rows, self.width, 4):
+            raise ValueError("accumulation checkpoint is %s, this context holds %s"
+                             % (a.shape, (self.local_rows, self.width, 4)))
+        self._check(self.lib.pt_load_accum(self._ctx, a.ctypes.data_as(C.c_void_p), a.nbytes))
 
     def stats(self):
         st = abi.PtStats()
@@ -172,18 +175,6 @@ class PathTracer:
                               out.ctypes.data_as(C.c_void_p), out.size, int(n))
         )
         return out
-
-
-_hip_lib = None
-
-
-def _hip():
-    global _hip_lib
-    if _hip_lib is None:
-        _hip_lib = C.CDLL("libamdhip64.so")
-        _hip_lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        _hip_lib.hipMemcpy.restype = C.c_int
-    return _hip_lib
 
 
 def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=None, geometry_path=None):

@@ -10,8 +10,7 @@ image.  Run where /root/reference exists:  python tests/golden/make_sky_fixture.
 """
 import json
 import os
-import struct
-import zlib
+import sys
 
 import numpy as np
 
@@ -19,50 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = "/root/reference/images/14.png"
 
 
-def read_png(path):
-    d = open(path, "rb").read()
-    assert d[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat = 8, b""
-    while pos < len(d):
-        (ln,) = struct.unpack(">I", d[pos:pos + 4])
-        typ, dat = d[pos + 4:pos + 8], d[pos + 8:pos + 8 + ln]
-        pos += 12 + ln
-        if typ == b"IHDR":
-            w, h, bd, ct, _, _, il = struct.unpack(">IIBBBBB", dat)
-        elif typ == b"IDAT":
-            idat += dat
-    assert bd == 8 and il == 0
-    ch = {2: 3, 6: 4}[ct]
-    raw = zlib.decompress(idat)
-    stride = w * ch
-    out = np.zeros((h, stride), np.uint8)
-    prev = np.zeros(stride, np.int32)
-    p = 0
-    for y in range(h):
-        f = raw[p]
-        line = np.frombuffer(raw[p + 1:p + 1 + stride], np.uint8).astype(np.int32)
-        p += 1 + stride
-        cur = line.copy()
-        if f == 1:
-            for i in range(ch, stride):
-                cur[i] = (cur[i] + cur[i - ch]) & 255
-        elif f == 2:
-            cur = (line + prev) & 255
-        elif f == 3:
-            for i in range(stride):
-                a = cur[i - ch] if i >= ch else 0
-                cur[i] = (cur[i] + ((a + prev[i]) >> 1)) & 255
-        elif f == 4:
-            for i in range(stride):
-                a = cur[i - ch] if i >= ch else 0
-                b = prev[i]
-                c = prev[i - ch] if i >= ch else 0
-                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[i] = (cur[i] + pr) & 255
-        out[y] = cur
-        prev = cur
-    return out.reshape(h, w, ch)
+sys.path.insert(0, os.path.dirname(HERE))
+from _png import read_png  # noqa: E402
 
 
 def main():

@@ -389,6 +389,93 @@ def test_error_behaviour(pt):
     assert pt.stats().segments == 0 and pt.stats().total_spp == 0
 
 
+def test_refused_repartition_leaves_the_context_as_it_was(ora):
+    """pt_set_params validates before it commits: a row partition the caller-bound accumulation
+    buffer cannot hold is refused and the previous partition keeps rendering correctly."""
+    import torch
+
+    sc = scenes.config1(64, 48, 2, 4)
+    p = sc.params.copy()
+    p.band_rows, p.band_index, p.band_count = 8, 0, 3   # rows 0-7, 24-31: 16 rows
+    t = PathTracer(64, 48)
+    t.set_spheres(sc.spheres)
+    t.set_params(p)
+    assert t.local_rows == 16
+    buf = torch.zeros((16, 64, 4), dtype=torch.float32, device="cuda")
+    t._check(t.lib.pt_bind_accum(t._ctx, C.c_void_p(buf.data_ptr()), buf.numel() * 4))
+    full = sc.params.copy()                              # all 48 rows do not fit the bound buffer
+    assert t.lib.pt_set_params(t._ctx, C.byref(full)) == abi.PT_ERR_CAPACITY
+    assert t.stats().local_rows == 16
+    t.render()                                           # still the 16-row band, inside the buffer
+    t.synchronize()
+    torch.cuda.synchronize()
+    ref, _ = ora.render(sc.spheres, p, 1)
+    assert_bit_equal(buf.cpu().numpy(), ref, "band render after a refused repartition")
+    t._check(t.lib.pt_bind_accum(t._ctx, None, 0))
+    t.close()
+
+
+def test_save_image_png_matches_the_rgba8_read_out(ora, tmp_path):
+    """Row f3: the reference's "Save Image" (src/dom.rs:126-143) — the resolved RGBA8 frame as a
+    PNG, file row 0 = top of the image = the LAST frame row (static/shader.frag:410)."""
+    from _png import read_png
+    from ray_tracer_webgl_amd import image_io
+
+    sc = scenes.default_scene(96, 54, spp=4, max_depth=8)
+    t, acc = render_scene(sc)
+    rgba = t.resolve_rgba8()
+    assert np.array_equal(rgba, ora.resolve_rgba8(acc, 4))
+    path = str(tmp_path / "frame.png")
+    image_io.write_png(path, rgba)
+    img = read_png(path)
+    assert img.shape == (54, 96, 3)
+    assert np.array_equal(img, rgba[::-1, :, :3])
+    # the sky is at the top of the file: bluer than the ground rows at the bottom
+    assert img[0, :, 2].mean() > img[-1, :, 2].mean()
+    # float read-out goes through the same quantisation
+    image_io.write_png(path, t.resolve())
+    assert np.array_equal(read_png(path), rgba[::-1, :, :3])
+    t.close()
+
+
+@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_BVH])
+def test_checkpoint_and_resume_is_bit_exact(ora, tmp_path, path):
+    """Row f3: render 4 passes, checkpoint, resume in a NEW context, render 4 more == 8
+    uninterrupted passes, bit for bit, sample count included (src/state.rs:443-450 semantics:
+    the accumulation state is the buffer + its frame count)."""
+    from ray_tracer_webgl_amd import image_io
+
+    sc = scenes.config2(96, 54, 2, 8, 12)
+    t8, full = render_scene(sc, geometry_path=path)
+    sc4 = scenes.config2(96, 54, 2, 4, 12)
+    t4, half = render_scene(sc4, geometry_path=path)
+    ck = str(tmp_path / "ck.npz")
+    image_io.save_accum(ck, half, t4.stats().total_spp)
+    t4.close()
+    acc, spp = image_io.load_accum(ck)
+    assert spp == 8
+    t = PathTracer(96, 54)
+    t.set_geometry_path(path)
+    t.set_spheres(sc.spheres)
+    q = sc.params.copy()
+    q.time = 4.0                                     # passes 4..7
+    t.set_params(q)
+    t.reserve_passes(4)
+    t.load_accum(acc)
+    assert t.stats().total_spp == 8
+    t.render_passes(4)
+    got = t.accum()
+    assert_bit_equal(got, full, "resumed vs uninterrupted")
+    assert t.stats().total_spp == 16
+    assert_bit_equal(t.resolve(), t8.resolve(), "resolved frames")
+    ref, _ = ora.render(sc.spheres, sc.params, 8)
+    assert_bit_equal(got, ref, "resumed vs oracle")
+    with pytest.raises(ValueError):
+        t.load_accum(acc[:10])
+    t.close()
+    t8.close()
+
+
 def test_resize_and_reuse(ora):
     sc = scenes.config1(48, 32, 2, 8)
     t = PathTracer(48, 32)
@@ -482,6 +569,40 @@ def test_render_is_hip_graph_capturable(ora):
     p1, _ = ora.render(sc.spheres, q, 1)
     expect = ((p0 + p1) + p0) + p1
     assert_bit_equal(got2[..., :3], expect[..., :3], "graph replay 2 adds the same passes again")
+    # read-out after replays the host never saw: the divisor comes from the device-side sample
+    # count (accum.w = 4 launches' worth of 4 spp), not from host bookkeeping
+    assert np.all(got2[..., 3] == 16.0)
+    assert_bit_equal(t.resolve(gamma=True), ora.resolve(expect, 16, gamma=True), "resolve after two replays")
+    assert np.array_equal(t.resolve_rgba8(), ora.resolve_rgba8(expect, 16))
+    assert t.stats().total_spp == 16
+    t.close()
+
+
+def test_resolve_before_any_replay_of_a_captured_launch_is_empty_not_wrong(ora):
+    """A capture that was never replayed has rendered nothing: read-out gives zeros (no host-side
+    sample count can claim otherwise)."""
+    import torch
+
+    sc = scenes.default_scene(64, 36, spp=2, max_depth=4)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t = PathTracer(64, 36, use_torch=True)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.render_passes(1)
+        torch.cuda.current_stream().synchronize()
+        t.reset()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            t.render_passes(1)
+    torch.cuda.synchronize()
+    out = t.resolve()
+    assert np.all(out[..., :3] == 0.0)
+    assert t.stats().total_spp == 0
+    g.replay()
+    torch.cuda.synchronize()
+    ref, _ = ora.render(sc.spheres, sc.params, 1)
+    assert_bit_equal(t.resolve(), ora.resolve(ref, 2), "resolve after the first replay")
     t.close()
 
 
