@@ -54,6 +54,13 @@ enum {
  *          at: boxes are inflated by a per-ray margin that covers the rounding of the literal
  *          test, so only spheres that cannot pass it are skipped (regular scenes of >= 16
  *          spheres; a scene without a hierarchy falls back to SCALAR)
+ *   GRID   a uniform grid built by pt_set_spheres (cells of about one sphere each, 3D-DDA walk,
+ *          entries registered with a margin that covers the rounding of the literal test and of
+ *          the walk): a ray looks at the entries of the cells it passes through, in order, and
+ *          stops once its closest root lies before the current cell's exit.  The better
+ *          structure when most rays start inside the scene (bounce rays): a hierarchy spends two
+ *          box tests per level just locating the ray's origin.  Same preconditions as BVH; a
+ *          scene without a grid falls back to BVH, then SCALAR
  *   AUTO   (default) after pt_set_spheres the first launch runs cold (unmeasured), the next
  *          ones measure one usable path each, and the fastest (time per camera sample) is
  *          used from then on                                                                 */
@@ -62,9 +69,14 @@ enum {
   PT_GEOM_LDS = 1,
   PT_GEOM_SCALAR = 2,
   PT_GEOM_BVH = 3,
+  PT_GEOM_GRID = 4,
 };
 enum {
   PT_OPT_GEOMETRY_PATH = 1,
+  PT_OPT_COUNT_WORK = 2,  /* 1: the walk kernels' measuring twins fill PtStats.work (slower; never time them) */
+  PT_OPT_CARRY_LANES = 3, /* walk kernels: move on to shading when fewer lanes than this (and less than half
+                             of the wave) are still walking; the stragglers continue in the next wave step.
+                             Scheduling only — images do not depend on it.  0 = lockstep.  Default 8. */
 };
 
 /* ---- background modes ----------------------------------------------------------------------- */
@@ -163,6 +175,16 @@ typedef struct PtStats {
   uint32_t bvh_slots;       /* + the spheres tested for every ray), how many of those, depth        */
   uint32_t bvh_outliers;
   uint32_t bvh_depth;
+  uint32_t grid_cells[3];   /* uniform grid of the current scene (0 = none): cells per axis,          */
+  uint32_t grid_entries;    /* entries (copies of a sphere, one per cell it is registered in + padding) */
+  uint32_t grid_always;     /* spheres tested for every ray                                            */
+  uint32_t _pad;
+  /* executed work of the walk kernels since the last reset, filled when PT_OPT_COUNT_WORK is on:
+   * [0] walk iterations (node steps / cell steps, wave-level)   [1] lanes active in them (sum)
+   * [2] leaf rounds (four literal tests per lane)               [3] lanes active in them
+   * [4] exact evaluations (sqrt + division), wave-level         [5] lanes active in them
+   * [6] wave steps                                              [7] lanes carried over (sum)   */
+  uint64_t work[8];
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -249,6 +271,17 @@ int pt_build_bvh(const PtSphere* spheres, uint32_t n, float* nodes, size_t node_
                  size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
                  uint32_t* counts5, uint32_t* nodes16, size_t n_words16, float* kscale,
                  float* nodes32, size_t n_floats32);
+/* The grid pt_set_spheres builds for PT_GEOM_GRID, on the host (no device needed; tests check the
+ * registration invariant): dims9 = {n[3] as floats' bit patterns are NOT used: see counts}, i.e.
+ * counts8 = {n.x, n.y, n.z, n_cell_entries, n_always, n_entries, max groups per cell, non-empty
+ * cells}; geom12 = {lo.xyz, h.xyz, hi.xyz, c0.xyz}; margin4 = {s0, rmin, rmax, d_near};
+ * delta_g = registration inflation; cells = n.x*n.y*n.z records (first group | groups << 24, a
+ * group = 4 entries), entries = 4 floats each {cx, cy, cz, r*r}, entry_index = original sphere
+ * index per entry (0xffffffff = padding).  Array pointers may be NULL (sizes only); capacities in
+ * elements.  PT_ERR_NOT_READY when the scene gets no grid, PT_ERR_CAPACITY when an array is too small. */
+int pt_build_grid(const PtSphere* spheres, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
+                  float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
+                  uint32_t* entry_index, size_t n_index);
 const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -28,9 +28,9 @@ PT_EMISSIVE = 3
 PT_BG_SKY = 0
 PT_BG_BLACK = 1
 
-PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH = 0, 1, 2, 3
-PT_OPT_GEOMETRY_PATH = 1
-GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh"}
+PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH, PT_GEOM_GRID = 0, 1, 2, 3, 4
+PT_OPT_GEOMETRY_PATH, PT_OPT_COUNT_WORK, PT_OPT_CARRY_LANES = 1, 2, 3
+GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh", 4: "grid"}
 
 f3 = C.c_float * 3
 d3 = C.c_double * 3
@@ -137,6 +137,11 @@ class PtStats(C.Structure):
         ("bvh_slots", C.c_uint32),
         ("bvh_outliers", C.c_uint32),
         ("bvh_depth", C.c_uint32),
+        ("grid_cells", C.c_uint32 * 3),
+        ("grid_entries", C.c_uint32),
+        ("grid_always", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("work", C.c_uint64 * 8),
     ]
 
 

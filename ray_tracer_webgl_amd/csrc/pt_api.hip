@@ -18,6 +18,7 @@
 
 #include "../../include/ptrace.h"
 #include "pt_bvh.hpp"
+#include "pt_grid.hpp"
 #include "pt_kernel_args.h"
 
 #define PT_API extern "C" __attribute__((visibility("default")))
@@ -59,12 +60,12 @@ struct pt_ctx {
   int geom_policy = PT_GEOM_AUTO;
   int geom_tuned = 0;              // the path PT_GEOM_AUTO settled on, 0 while measuring
   int geom_last = PT_GEOM_LDS;     // path of the most recent launch
-  int trial_paths[3] = {0, 0, 0};  // the paths this scene can use, in measuring order
+  int trial_paths[4] = {0, 0, 0, 0};  // the paths this scene can use, in measuring order
   int n_trials = 0;
   int trial_state = 0;             // 0: unmeasured first launch (cold), k in 1..n_trials: the next
                                    // launch measures trial_paths[k-1], n_trials+1: all enqueued
-  hipEvent_t trial_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // begin/end per trial
-  double trial_samples[3] = {0.0, 0.0, 0.0};
+  hipEvent_t trial_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // begin/end per trial
+  double trial_samples[4] = {0.0, 0.0, 0.0, 0.0};
   // culling hierarchy (PT_GEOM_BVH), rebuilt by pt_set_spheres; absent for tiny / irregular scenes
   bool have_bvh = false;
   uint32_t* d_bvh_nodes = nullptr;
@@ -74,6 +75,15 @@ struct pt_ctx {
   size_t bvh_node_cap = 0, bvh_slot_cap = 0;
   uint32_t bvh_n_nodes = 0, bvh_n_slots = 0, bvh_n_tree_slots = 0, bvh_n_outliers = 0, bvh_depth = 0;
   float bvh_c0[3] = {0, 0, 0}, bvh_s0 = 0, bvh_kinv = 1;
+  // uniform grid (PT_GEOM_GRID), rebuilt by pt_set_spheres; absent for tiny / irregular scenes
+  bool have_grid = false;
+  uint32_t* d_grid_cells = nullptr;
+  float* d_grid_entries = nullptr;
+  uint32_t* d_grid_index = nullptr;
+  size_t grid_cell_cap = 0, grid_entry_cap = 0;
+  ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
+  int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
+  uint32_t carry_lanes = 8;
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -89,8 +99,6 @@ struct pt_ctx {
   int num_cus = 256;
   int max_lds = 65536;
   std::string error;
-  unsigned long long* dbg_timeline = nullptr; // -DPT_TIMELINE dev builds
-  size_t dbg_timeline_n = 0;
 };
 
 namespace {
@@ -194,6 +202,7 @@ void list_paths(pt_ctx* c) {
   if (c->n_spheres <= PT_MAX_SPHERES_LDS) c->trial_paths[c->n_trials++] = PT_GEOM_LDS;
   c->trial_paths[c->n_trials++] = PT_GEOM_SCALAR;
   if (c->have_bvh) c->trial_paths[c->n_trials++] = PT_GEOM_BVH;
+  if (c->have_grid) c->trial_paths[c->n_trials++] = PT_GEOM_GRID;
 }
 
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
@@ -259,6 +268,10 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
+  for (const void* k : {reinterpret_cast<const void*>(pt_trace_kernel_grid), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells),
+                        reinterpret_cast<const void*>(pt_trace_kernel_grid_gmem), reinterpret_cast<const void*>(pt_trace_kernel_bvh_count),
+                        reinterpret_cast<const void*>(pt_trace_kernel_grid_count), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count)})
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -277,6 +290,9 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_bvh_nodes32) (void)hipFree(c->d_bvh_nodes32);
   if (c->d_bvh_slots) (void)hipFree(c->d_bvh_slots);
   if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
+  if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
+  if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
+  if (c->d_grid_index) (void)hipFree(c->d_grid_index);
   if (c->own_accum) (void)hipFree(c->own_accum);
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_resolve) (void)hipFree(c->d_resolve);
@@ -345,6 +361,9 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   // the culling hierarchy of PT_GEOM_BVH (regular scenes of at least 16 spheres)
   ptbvh::Bvh bvh;
   const bool have_bvh = regular && ptbvh::build(geom.data(), radii.data(), n, &bvh);
+  // ... and the uniform grid of PT_GEOM_GRID (same precondition)
+  ptgrid::Grid grid;
+  const bool have_grid = regular && ptgrid::build(geom.data(), radii.data(), n, &grid);
   {
     // the stream may still be reading the previous scene
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -382,6 +401,38 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     c->bvh_s0 = bvh.s0;
     c->bvh_kinv = bvh.kinv;
     c->have_bvh = true;
+  }
+  c->have_grid = false;
+  if (have_grid) {
+    const size_t n_cells_pad = (grid.cells.size() + 3u) & ~(size_t)3u;  // the kernels stage 16 B at a time
+    if (n_cells_pad > c->grid_cell_cap) {
+      if (c->d_grid_cells) PT_HIP(c, hipFree(c->d_grid_cells));
+      c->d_grid_cells = nullptr; c->grid_cell_cap = 0;
+      PT_HIP(c, hipMalloc(&c->d_grid_cells, n_cells_pad * sizeof(uint32_t)));
+      c->grid_cell_cap = n_cells_pad;
+    }
+    // + one group of slack: lanes without a cell under test read (and discard) the group their
+    // stale record points at, which may be the one behind the last
+    const size_t n_ent_pad = (size_t)grid.n_entries + 4u;
+    if (n_ent_pad > c->grid_entry_cap) {
+      if (c->d_grid_entries) PT_HIP(c, hipFree(c->d_grid_entries));
+      if (c->d_grid_index) PT_HIP(c, hipFree(c->d_grid_index));
+      c->d_grid_entries = nullptr; c->d_grid_index = nullptr; c->grid_entry_cap = 0;
+      PT_HIP(c, hipMalloc(&c->d_grid_entries, n_ent_pad * 16));
+      PT_HIP(c, hipMalloc(&c->d_grid_index, n_ent_pad * sizeof(uint32_t)));
+      c->grid_entry_cap = n_ent_pad;
+    }
+    PT_HIP(c, hipMemset(c->d_grid_cells, 0, n_cells_pad * sizeof(uint32_t)));
+    PT_HIP(c, hipMemcpy(c->d_grid_cells, grid.cells.data(), grid.cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemset(c->d_grid_entries, 0, n_ent_pad * 16));
+    PT_HIP(c, hipMemcpy(c->d_grid_entries, grid.entries.data(), (size_t)grid.n_entries * 16, hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemset(c->d_grid_index, 0xff, n_ent_pad * sizeof(uint32_t)));
+    PT_HIP(c, hipMemcpy(c->d_grid_index, grid.entry_index.data(), (size_t)grid.n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+    grid.cells.clear(); grid.cells.shrink_to_fit();
+    grid.entries.clear(); grid.entries.shrink_to_fit();
+    grid.entry_index.clear(); grid.entry_index.shrink_to_fit();
+    c->grid = grid;
+    c->have_grid = true;
   }
   c->n_spheres = n;
   c->geom_tuned = 0;  // a new scene: PT_GEOM_AUTO measures again
@@ -582,7 +633,6 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.counters = c->d_counters;
   A.tile_order = c->d_tile_order;
   A.tile_cost = c->d_tile_cost;
-  A.timeline = nullptr;
 
   // which way PHASE 1 looks at the sphere list (bit-identical results whichever way)
   int path = c->geom_policy;
@@ -595,6 +645,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     else path = c->trial_paths[0]; // trials still in flight
   }
   // a forced path the scene cannot use falls back to the nearest one it can
+  if (path == PT_GEOM_GRID && !c->have_grid) path = c->have_bvh ? PT_GEOM_BVH : PT_GEOM_SCALAR;
   if (path == PT_GEOM_BVH && !c->have_bvh) path = PT_GEOM_SCALAR;
   if (path == PT_GEOM_LDS && c->n_spheres > PT_MAX_SPHERES_LDS) path = PT_GEOM_SCALAR;
   c->geom_last = path;
@@ -604,38 +655,73 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   const void* kfn = nullptr;
   uint32_t bvh_block = 0;
   A.coop_max_live = 16;
-  if (path == PT_GEOM_BVH) {
-    A.bvh_nodes = c->d_bvh_nodes;
-    A.bvh_nodes32 = c->d_bvh_nodes32;
-    A.bvh_slots = c->d_bvh_slots;
-    A.bvh_slot_index = c->d_bvh_index;
-    A.n_nodes = c->bvh_n_nodes;
-    A.n_tree_slots = c->bvh_n_tree_slots;
-    A.n_slots = c->bvh_n_slots;
-    A.n_outliers = c->bvh_n_outliers;
-    for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
-    A.bvh_s0 = c->bvh_s0;
-    A.bvh_kinv = c->bvh_kinv;
+  A.carry_lanes = c->carry_lanes;
+  if (path == PT_GEOM_BVH || path == PT_GEOM_GRID) {
+    const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
+    const size_t park1024 = (size_t)PT_PARK_STRIDE * 4 * 1024;
+    size_t scene = 0;
+    if (path == PT_GEOM_BVH) {
+      A.bvh_nodes = c->d_bvh_nodes;
+      A.bvh_nodes32 = c->d_bvh_nodes32;
+      A.bvh_slots = c->d_bvh_slots;
+      A.bvh_slot_index = c->d_bvh_index;
+      A.n_nodes = c->bvh_n_nodes;
+      A.n_tree_slots = c->bvh_n_tree_slots;
+      A.n_slots = c->bvh_n_slots;
+      A.n_outliers = c->bvh_n_outliers;
+      for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
+      A.bvh_s0 = c->bvh_s0;
+      A.bvh_kinv = c->bvh_kinv;
+      // dynamic LDS = staged scene + the parked path state of every lane of the workgroup
+      const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
+      const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
+      if (need_all + park1024 <= lds_max) {
+        scene = need_all;
+        kfn = c->count_work ? reinterpret_cast<const void*>(pt_trace_kernel_bvh_count)
+                            : reinterpret_cast<const void*>(pt_trace_kernel_bvh);
+      } else if (need_nodes + park1024 <= lds_max) {
+        scene = need_nodes;
+        kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes);
+      } else {
+        kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem);
+      }
+    } else {
+      const ptgrid::Grid& g = c->grid;
+      A.bvh_slots = c->d_grid_entries;
+      A.bvh_slot_index = c->d_grid_index;
+      A.grid_cells = c->d_grid_cells;
+      A.n_cells = g.n[0] * g.n[1] * g.n[2];
+      A.n_tree_slots = g.n_cell_entries;
+      A.n_slots = g.n_entries;
+      A.n_outliers = g.n_always;
+      for (int k = 0; k < 3; k++) {
+        A.bvh_c0[k] = g.c0[k];
+        A.grid_n[k] = g.n[k];
+        A.grid_lo[k] = g.lo[k]; A.grid_hi[k] = g.hi[k];
+        A.grid_h[k] = g.h[k]; A.grid_inv_h[k] = g.inv_h[k];
+      }
+      A.bvh_s0 = g.s0;
+      A.grid_d_near = g.d_near;
+      const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
+      const size_t need_all = need_cells + (size_t)g.n_entries * 16;
+      if (need_all + park1024 <= lds_max) {
+        scene = need_all;
+        kfn = c->count_work ? reinterpret_cast<const void*>(pt_trace_kernel_grid_count)
+                            : reinterpret_cast<const void*>(pt_trace_kernel_grid);
+      } else if (need_cells + park1024 <= lds_max) {
+        scene = need_cells;
+        kfn = c->count_work ? reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count)
+                            : reinterpret_cast<const void*>(pt_trace_kernel_grid_cells);
+      } else {
+        kfn = reinterpret_cast<const void*>(pt_trace_kernel_grid_gmem);
+      }
+    }
+    A.lds_scene_bytes = (uint32_t)scene;
     // tail mode costs ~n/64 rounds per live ray, the walk a roughly constant ~1500 issue slots
     // per wave: the turn-around only pays for the last few rays of a wave
     uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
     uint32_t lim = 1500u / per_ray;
     A.coop_max_live = lim > 16u ? 16u : lim;
-    // dynamic LDS = staged scene + the parked path state of every lane of the workgroup
-    const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
-    const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
-    const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
-    const size_t park1024 = (size_t)PT_PARK_STRIDE * 4 * 1024;
-    size_t scene = 0;
-    if (need_all + park1024 <= lds_max) {
-      scene = need_all;
-      kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh);
-    } else if (need_nodes + park1024 <= lds_max) {
-      scene = need_nodes;
-      kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes);
-    } else {
-      kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem);
-    }
     // workgroup size: whichever of 256 / 512 / 1024 threads puts the most waves on a CU (the
     // staged scene is paid once per workgroup, the parked state and the VGPRs per wave)
     int best_waves = -1;
@@ -652,6 +738,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       uint32_t b = (uint32_t)atoi(e);
       if (b == 256u || b == 512u || b == 1024u) bvh_block = b;
     }
+    if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
 #endif
     if (!bvh_block) bvh_block = 1024u;
     lds = scene + (size_t)PT_PARK_STRIDE * 4 * bvh_block;
@@ -688,15 +775,6 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
   if (grid < 1) grid = 1;
-#ifdef PT_TIMELINE
-  {
-    static unsigned long long* tl = nullptr; static size_t tl_cap = 0;
-    size_t need_tl = (size_t)grid * (block / 64) * 8;
-    if (need_tl > tl_cap) { if (tl) (void)hipFree(tl); PT_HIP(c, hipMalloc(&tl, need_tl * 8)); tl_cap = need_tl; }
-    A.timeline = tl;
-    c->dbg_timeline = tl; c->dbg_timeline_n = need_tl;
-  }
-#endif
 
   // inside a stream capture (hipGraph) nothing may synchronise and timing events are
   // meaningless: skip the event pair, the launch sequence itself is capture-safe
@@ -761,16 +839,6 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 
 PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
 
-#ifdef PT_TIMELINE
-// dev builds only: copy the last launch's per-wave timeline (8 u64 per wave) to the host
-extern "C" __attribute__((visibility("default"))) long pt_debug_timeline(pt_ctx* c, unsigned long long* out, size_t cap) {
-  if (!c || !c->dbg_timeline) return -1;
-  (void)hipStreamSynchronize(c->stream);
-  size_t n = c->dbg_timeline_n < cap ? c->dbg_timeline_n : cap;
-  if (hipMemcpy(out, c->dbg_timeline, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -2;
-  return (long)n;
-}
-#endif
 
 PT_API int pt_synchronize(pt_ctx* c) {
   if (!c) return PT_ERR_INVALID;
@@ -828,19 +896,6 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   unsigned long long ctr[PT_CTR_COUNT];
   PT_HIP(c, hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
   memset(out, 0, sizeof *out);
-#ifdef PT_TIMELINE
-  fprintf(stderr, "TIMELINE iters %llu phase3_entries %llu phase3_spheres %llu phase2_iters %llu overflow_lanes %llu\n", ctr[3], ctr[4], ctr[5], ctr[6], ctr[7]);
-  {
-    double tot = 0; for (int k = 8; k < 15; k++) tot += (double)ctr[k];
-    fprintf(stderr, "TIMELINE items longer than 384: %llu  768: %llu  1536: %llu  2304: %llu  3000: %llu segments (exclusive buckets)\n",
-            ctr[16], ctr[17], ctr[18], ctr[19], ctr[20]);
-    fprintf(stderr, "TIMELINE node-loop occupancy by iteration index (x4): ");
-    for (int k = 0; k < 20; k++) fprintf(stderr, "[%d] %.1f lanes x %.3f of steps  ", 4 * k, ctr[44 + k] ? (double)ctr[24 + k] / ctr[44 + k] : 0.0, ctr[3] ? (double)ctr[44 + k] / 4.0 / ctr[3] : 0.0);
-    fprintf(stderr, "\n");
-    fprintf(stderr, "TIMELINE wall-time shares: refill+camera %.3f  setup+outliers %.3f  node loops %.3f  leaf loops %.3f  final drain %.3f  shading %.3f  tail mode %.3f\n",
-            ctr[8] / tot, ctr[9] / tot, ctr[10] / tot, ctr[11] / tot, ctr[12] / tot, ctr[13] / tot, ctr[14] / tot);
-  }
-#endif
   out->segments = ctr[PT_CTR_SEGMENTS];
   out->samples = c->samples;
   out->sphere_tests = ctr[PT_CTR_SEGMENTS] * (uint64_t)c->n_spheres;
@@ -857,6 +912,12 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   out->local_rows = c->local_rows;
   out->geometry_path = (uint32_t)c->geom_last;
   out->geometry_tuned = c->geom_tuned ? 1u : 0u;
+  for (int k = 0; k < 8; k++) out->work[k] = ctr[PT_CTR_WORK + k];
+  if (c->have_grid) {
+    for (int k = 0; k < 3; k++) out->grid_cells[k] = c->grid.n[k];
+    out->grid_entries = c->grid.n_entries;
+    out->grid_always = c->grid.n_always;
+  }
   if (c->have_bvh) {
     out->bvh_nodes = c->bvh_n_nodes;
     out->bvh_slots = c->bvh_n_slots;
@@ -869,9 +930,19 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
 PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   if (!c) return PT_ERR_INVALID;
   if (key == PT_OPT_GEOMETRY_PATH) {
-    if (value != PT_GEOM_AUTO && value != PT_GEOM_LDS && value != PT_GEOM_SCALAR && value != PT_GEOM_BVH)
+    if (value != PT_GEOM_AUTO && value != PT_GEOM_LDS && value != PT_GEOM_SCALAR && value != PT_GEOM_BVH &&
+        value != PT_GEOM_GRID)
       return fail(c, PT_ERR_INVALID, "pt_set_option: bad geometry path %d", value);
     c->geom_policy = value;
+    return PT_OK;
+  }
+  if (key == PT_OPT_COUNT_WORK) { // measuring twin of the walk kernels (PtStats.work); slower, never timed
+    c->count_work = value ? 1 : 0;
+    return PT_OK;
+  }
+  if (key == PT_OPT_CARRY_LANES) { // 0 = lockstep to the last lane; scheduling only, never results
+    if (value < 0 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: carry lanes %d", value);
+    c->carry_lanes = (uint32_t)value;
     return PT_OK;
   }
   return fail(c, PT_ERR_INVALID, "pt_set_option: unknown key %d", key);

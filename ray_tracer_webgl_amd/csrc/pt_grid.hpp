@@ -1,0 +1,294 @@
+// pt_grid.hpp — host-side construction of the uniform grid used by the PT_GEOM_GRID trace
+// kernels (pt_kernels.hip).  Header-only; included by pt_api.hip and pt_host.cpp.
+//
+// Like the hierarchy of pt_bvh.hpp this structure only decides WHICH spheres a ray looks at;
+// every sphere that is looked at runs the literal fp32 test of static/shader.frag:145-173, and
+// hit_world's result (:175-196) is order-free: the lexicographic minimum of (root, -index) over
+// the spheres whose test accepts (proof sketch in pt_kernels.hip).  A grid is the better
+// culling structure for what BASELINE's scenes are — many small spheres of similar size — because
+// a bounce ray starts INSIDE the scene: a tree spends ~2 box tests per level (17 of the ~18 nodes
+// a config-2 ray visits) just descending to the leaf around the ray's origin, a grid starts in
+// the right cell.
+//
+// What may be skipped.  For a regular ray and sphere, with o' = o - C, forward
+// error analysis of the literal test (oc, half_b, c, discriminant in fp32 with the fused forms of
+// PT-SPEC, u = 2^-24) gives |disc_fp32 - disc_exact| <= |d|^2 E, E = u (18 |o'|^2 + 7 r^2), and
+// for the root v the shader would accept (either sign of the square root, fp32 sqrt and divide)
+//
+//     |P(v) - C|^2  <=  r^2 + E',     E' = u (32 |o'|^2 + 20 r^2),     P(t) = o + t d
+//
+// (|P(v)-C|^2 - r^2 = |d|^2 (v - t_ca)^2 - disc_exact / |d|^2; the first term is disc_fp32 / |d|^2
+// up to the rounding of half_b, |d|^2, sqrt and the division, each of relative size a few u,
+// which the gap between 18/7 and 32/20 covers).  Hence a sphere can only be hit at a point within
+//
+//     delta(D) = sqrt(rmin^2 + 32 u D^2) - rmin + 10 u rmax,        D >= |o - C|
+//
+// of its surface (sqrt(r^2 + x) - r decreases with r), i.e. inside its bounding box inflated by
+// delta.  With D = |o - c0| + s0 (s0 = max |C - c0| + |r| over the gridded spheres) that is a
+// per-RAY bound; the grid registers every sphere in all cells its box inflated by
+//
+//     delta_g = delta(d_near) + eps_dda
+//
+// touches, and rays with |o - c0| + s0 <= d_near (= 3 s0: every ray that starts within 2 s0 of
+// the scene's middle) walk the cells.  The rare ray from farther away first tests the grid's
+// bounding box inflated by its own delta(D); if it misses, no gridded sphere can be hit; if it
+// enters, the lane falls back to the literal loop over the whole list (measured on config 2 and
+// config 5: 0 and 2e-5 of the rays).  eps_dda covers the walk's own rounding: the 3D-DDA's
+// boundary-crossing times are sums of up to n per-axis increments, each rounded, so the cell
+// the walk stands in at its time t is within (n + 8) u |d| t of the cell that contains the exact
+// P(t); the slab test of the entry point and the evaluation of the cell boundaries are of the
+// same size.  The walk ends when it leaves the grid or when the closest accepted root lies
+// strictly before the current cell's exit time: a sphere not tested yet is registered only in
+// cells the walk reaches later, so its root is not smaller.
+//
+// Spheres that would be registered in very many cells — far-out giants (the ground), and spheres
+// much larger than a cell — stay out of the cells and are tested for every ray through scalar
+// loads, as the list kernels test every sphere (at most kMaxAlways).
+//
+// Layout produced:
+//   cells   : n[0]*n[1]*n[2] records, x fastest: first group | n_groups << 24; a GROUP is four
+//             consecutive entries (the unit one leaf round of the kernel tests)
+//   entries : {cx, cy, cz, r*r} copies; the cells' groups first (padded with entries that can
+//             never pass: r*r = -inf), then the always-tested spheres (padded to four)
+//   entry_index : original sphere index per entry (0xffffffff = padding)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace ptgrid {
+
+constexpr uint32_t kMaxAlways = 32;   // spheres tested for every ray
+constexpr uint32_t kMaxGroups = 255;  // groups of four entries per cell (8-bit field)
+constexpr uint32_t kMaxAxis = 1023;   // cells per axis (10-bit fields in the walk's step counter)
+
+struct Grid {
+  uint32_t n[3] = {1, 1, 1};
+  float lo[3] = {0, 0, 0}, h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};
+  float hi[3] = {0, 0, 0};  // lo + n * h, rounded up
+  std::vector<uint32_t> cells;
+  std::vector<float> entries;
+  std::vector<uint32_t> entry_index;
+  uint32_t n_cell_entries = 0, n_always = 0, n_entries = 0;
+  float c0[3] = {0, 0, 0};
+  float s0 = 0, rmin = 0, rmax = 0;
+  float d_near = 0;   // rays with |o - c0|_2 + s0 <= d_near may walk the cells
+  float delta_g = 0;  // registration inflation
+  uint32_t max_groups = 0, nonempty = 0;
+};
+
+inline float round_up(double v) {
+  float f = (float)v;
+  return (double)f < v ? std::nextafterf(f, std::numeric_limits<float>::infinity()) : f;
+}
+inline float round_down(double v) {
+  float f = (float)v;
+  return (double)f > v ? std::nextafterf(f, -std::numeric_limits<float>::infinity()) : f;
+}
+
+// delta(D) as the kernel evaluates it must not be smaller than this (the kernel adds slack)
+inline double delta_of(double rmin, double rmax, double D) {
+  const double u = 5.9604644775390625e-08;
+  return std::sqrt(rmin * rmin + 32.0 * u * D * D) - rmin + 10.0 * u * rmax;
+}
+
+// geom: n x {cx, cy, cz, r*r} as the list kernels read it; radius: n signed radii; all finite
+// (the caller only builds for scenes it classified as regular).  Returns false when a grid
+// would be useless or cannot be represented; the other paths are used then.
+inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out) {
+  *out = Grid();
+  if (n < 16) return false;
+  // ---- far-out giants (same rule as pt_bvh.hpp) ---------------------------------------------
+  double med[3];
+  {
+    std::vector<float> tmp(n);
+    for (int k = 0; k < 3; k++) {
+      for (uint32_t i = 0; i < n; i++) tmp[i] = geom[4 * i + k];
+      std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+      med[k] = tmp[n / 2];
+    }
+  }
+  std::vector<double> reach(n);
+  for (uint32_t i = 0; i < n; i++) {
+    double dx = geom[4 * i] - med[0], dy = geom[4 * i + 1] - med[1], dz = geom[4 * i + 2] - med[2];
+    reach[i] = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)radius[i]);
+  }
+  std::vector<uint32_t> by_reach(n);
+  for (uint32_t i = 0; i < n; i++) by_reach[i] = i;
+  std::sort(by_reach.begin(), by_reach.end(), [&](uint32_t a, uint32_t b) { return reach[a] < reach[b]; });
+  const double ref = reach[by_reach[(size_t)(0.9 * (n - 1))]];
+  std::vector<uint8_t> always(n, 0);
+  uint32_t n_always = 0;
+  for (uint32_t k = n; k-- > 0 && n_always < kMaxAlways;) {
+    if (reach[by_reach[k]] > 8.0 * ref) { always[by_reach[k]] = 1; n_always++; } else break;
+  }
+  if (n - n_always < 8) return false;
+
+  // ---- cell edge: about one sphere per cell of the occupied volume; flat axes get one layer --
+  std::vector<float> rs;
+  double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+  for (uint32_t i = 0; i < n; i++) {
+    if (always[i]) continue;
+    rs.push_back(std::fabs(radius[i]));
+    for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], (double)geom[4 * i + k]); chi[k] = std::max(chi[k], (double)geom[4 * i + k]); }
+  }
+  std::nth_element(rs.begin(), rs.begin() + rs.size() / 2, rs.end());
+  const double rmed = std::max((double)rs[rs.size() / 2], 1e-30);
+  const double cnt = (double)rs.size();
+  double ext[3];
+  for (int k = 0; k < 3; k++) ext[k] = std::max(chi[k] - clo[k], 2.0 * rmed);
+  double edge = std::cbrt(ext[0] * ext[1] * ext[2] / (cnt / 2.0));
+  for (int it = 0; it < 3; it++) {
+    double v = 1.0; int free_axes = 0;
+    for (int k = 0; k < 3; k++) if (ext[k] > 1.5 * edge) { v *= ext[k]; free_axes++; }
+    if (free_axes) edge = std::pow(v / (cnt / 2.0), 1.0 / free_axes);
+  }
+  edge *= 0.7;
+  if (!(edge > 0.0) || !std::isfinite(edge)) return false;
+
+  for (int attempt = 0; attempt < 4; attempt++, edge *= 0.6) {
+    // spheres much larger than a cell would be copied into many cells: test them for every ray
+    std::vector<uint8_t> alw = always;
+    uint32_t n_alw = n_always;
+    {
+      std::vector<uint32_t> big;
+      for (uint32_t i = 0; i < n; i++) if (!alw[i] && std::fabs((double)radius[i]) > 0.5 * edge) big.push_back(i);
+      std::sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { return std::fabs(radius[a]) > std::fabs(radius[b]); });
+      for (uint32_t i : big) {
+        if (n_alw >= kMaxAlways) break;  // the rest is gridded, at the price of copies
+        if (std::fabs((double)radius[i]) > 1.0 * edge || big.size() <= kMaxAlways - n_always) { alw[i] = 1; n_alw++; }
+      }
+    }
+    if (n - n_alw < 8) return false;
+    // ---- margin constants over the gridded spheres ----------------------------------------
+    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+    double rmin = 1e300, rmax = 0.0;
+    clo[0] = clo[1] = clo[2] = 1e300; chi[0] = chi[1] = chi[2] = -1e300;
+    for (uint32_t i = 0; i < n; i++) {
+      if (alw[i]) continue;
+      const double r = std::fabs((double)radius[i]);
+      rmin = std::min(rmin, r); rmax = std::max(rmax, r);
+      for (int k = 0; k < 3; k++) {
+        clo[k] = std::min(clo[k], (double)geom[4 * i + k]); chi[k] = std::max(chi[k], (double)geom[4 * i + k]);
+        blo[k] = std::min(blo[k], (double)geom[4 * i + k] - r); bhi[k] = std::max(bhi[k], (double)geom[4 * i + k] + r);
+      }
+    }
+    Grid g;
+    for (int k = 0; k < 3; k++) g.c0[k] = (float)(0.5 * (clo[k] + chi[k]));
+    double s0 = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (alw[i]) continue;
+      double dx = geom[4 * i] - (double)g.c0[0], dy = geom[4 * i + 1] - (double)g.c0[1], dz = geom[4 * i + 2] - (double)g.c0[2];
+      s0 = std::max(s0, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)radius[i]));
+    }
+    g.s0 = round_up(s0 * (1.0 + 1e-6));
+    g.rmin = round_down(rmin); g.rmax = round_up(rmax);
+    g.d_near = round_up(3.0 * (double)g.s0);
+    // ---- resolution --------------------------------------------------------------------------
+    double diag = 0.0;
+    uint32_t n_sum = 0;
+    double dg = 0.0;
+    bool ok = true;
+    // the bounds are built with an inflation dg that must cover what it needs itself (it depends,
+    // weakly, on the resolution and the extent): iterate to a fixed point
+    for (int pass = 0; pass < 16; pass++) {
+      diag = 0.0; n_sum = 0; ok = true;
+      for (int k = 0; k < 3; k++) {
+        const double a = blo[k] - dg, b = bhi[k] + dg;
+        double cells = std::floor((b - a) / edge + 0.5);
+        if (cells < 1.0) cells = 1.0;
+        if (cells > (double)kMaxAxis) { ok = false; cells = kMaxAxis; }
+        g.n[k] = (uint32_t)cells;
+        g.lo[k] = round_down(a);
+        g.h[k] = round_up((b - (double)g.lo[k]) / cells * (1.0 + 1e-6));
+        g.inv_h[k] = (float)(1.0 / (double)g.h[k]);
+        g.hi[k] = round_up((double)g.lo[k] + cells * (double)g.h[k]);
+        diag += ((double)g.hi[k] - g.lo[k]) * ((double)g.hi[k] - g.lo[k]);
+        n_sum += g.n[k];
+      }
+      diag = std::sqrt(diag);
+      const double u = 5.9604644775390625e-08;
+      const double eps_dda = 32.0 * (n_sum + 8.0) * u * ((double)g.d_near + diag);
+      // the kernel's per-ray delta carries 25 % slack on E' and is compared against this value
+      const double need = (std::sqrt(rmin * rmin + 32.0 * 1.25 * u * (double)g.d_near * g.d_near) - rmin + 16.0 * u * rmax) + eps_dda;
+      if (need <= dg) break;
+      dg = need * 1.02;
+      ok = false;  // not settled yet
+    }
+    if (!ok) return false;
+    g.delta_g = round_up(dg);
+    const size_t n_cells = (size_t)g.n[0] * g.n[1] * g.n[2];
+    if (n_cells > (1u << 22)) return false;
+    // ---- registration --------------------------------------------------------------------------
+    std::vector<uint32_t> count(n_cells, 0);
+    auto range = [&](uint32_t i, int k, uint32_t& a, uint32_t& b) {
+      const double r = std::fabs((double)radius[i]) + (double)g.delta_g;
+      double fa = std::floor(((double)geom[4 * i + k] - r - (double)g.lo[k]) / (double)g.h[k]);
+      double fb = std::floor(((double)geom[4 * i + k] + r - (double)g.lo[k]) / (double)g.h[k]);
+      fa = std::min(std::max(fa, 0.0), (double)g.n[k] - 1.0);
+      fb = std::min(std::max(fb, 0.0), (double)g.n[k] - 1.0);
+      a = (uint32_t)fa; b = (uint32_t)fb;
+    };
+    for (int fill = 0; fill < 2; fill++) {
+      std::vector<uint32_t> cursor;
+      if (fill) {
+        // groups of four per cell
+        g.cells.assign(n_cells, 0);
+        uint32_t group = 0;
+        g.max_groups = 0; g.nonempty = 0;
+        for (size_t c = 0; c < n_cells; c++) {
+          const uint32_t ng = (count[c] + 3u) / 4u;
+          if (ng > kMaxGroups) { ok = false; break; }
+          g.cells[c] = group | (ng << 24);
+          group += ng;
+          g.max_groups = std::max(g.max_groups, ng);
+          g.nonempty += ng ? 1u : 0u;
+          if (group >= (1u << 24)) { ok = false; break; }
+        }
+        if (!ok) break;
+        g.n_cell_entries = group * 4u;
+        g.entries.assign((size_t)g.n_cell_entries * 4, 0.f);
+        g.entry_index.assign(g.n_cell_entries, 0xffffffffu);
+        for (uint32_t e = 0; e < g.n_cell_entries; e++) g.entries[4 * (size_t)e + 3] = -std::numeric_limits<float>::infinity();
+        cursor.assign(n_cells, 0);
+      }
+      for (uint32_t i = 0; i < n; i++) {  // ascending index: deterministic layout
+        if (alw[i]) continue;
+        uint32_t a[3], b[3];
+        for (int k = 0; k < 3; k++) range(i, k, a[k], b[k]);
+        for (uint32_t z = a[2]; z <= b[2]; z++)
+          for (uint32_t y = a[1]; y <= b[1]; y++)
+            for (uint32_t x = a[0]; x <= b[0]; x++) {
+              const size_t c = ((size_t)z * g.n[1] + y) * g.n[0] + x;
+              if (!fill) { count[c]++; continue; }
+              const uint32_t e = (g.cells[c] & 0xffffffu) * 4u + cursor[c]++;
+              std::memcpy(&g.entries[4 * (size_t)e], geom + 4 * (size_t)i, 16);
+              g.entry_index[e] = i;
+            }
+      }
+    }
+    if (!ok) continue;  // a cell overflowed: finer cells
+    // ---- the always-tested spheres, ascending index, padded to four -----------------------------
+    for (uint32_t i = 0; i < n; i++) {
+      if (!alw[i]) continue;
+      g.entries.insert(g.entries.end(), geom + 4 * (size_t)i, geom + 4 * (size_t)i + 4);
+      g.entry_index.push_back(i);
+    }
+    g.n_always = n_alw;
+    while ((g.entry_index.size() & 3u) != 0) {
+      const float pad[4] = {0.f, 0.f, 0.f, -std::numeric_limits<float>::infinity()};
+      g.entries.insert(g.entries.end(), pad, pad + 4);
+      g.entry_index.push_back(0xffffffffu);
+    }
+    g.n_entries = (uint32_t)g.entry_index.size();
+    if (g.n_entries > (1u << 24)) return false;
+    *out = std::move(g);
+    return true;
+  }
+  return false;
+}
+
+}  // namespace ptgrid

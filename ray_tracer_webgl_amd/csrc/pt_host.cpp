@@ -3,6 +3,7 @@
 #include "pt_host.hpp"
 
 #include "pt_bvh.hpp"
+#include "pt_grid.hpp"
 
 #include <new>
 
@@ -126,6 +127,40 @@ static pt::Sphere from_host(const PtHostSphere& h) {
 }
 
 // the hierarchy of PT_GEOM_BVH exactly as pt_set_spheres (pt_api.hip) builds and uploads it
+PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
+                         float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
+                         uint32_t* entry_index, size_t n_index) {
+  if (!s && n) return PT_ERR_INVALID;
+  std::vector<float> geom((size_t)n * 4), radii(n);
+  bool regular = true;
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) {
+      regular = regular && (std::fabs(s[i].center[k]) < 1e15f);
+      geom[4 * (size_t)i + k] = s[i].center[k];
+    }
+    regular = regular && (std::fabs(s[i].radius) < 1e15f);
+    geom[4 * (size_t)i + 3] = s[i].radius * s[i].radius;
+    radii[i] = s[i].radius;
+  }
+  ptgrid::Grid g;
+  if (!regular || !ptgrid::build(geom.data(), radii.data(), n, &g)) return PT_ERR_NOT_READY;
+  if (counts8) {
+    counts8[0] = g.n[0]; counts8[1] = g.n[1]; counts8[2] = g.n[2]; counts8[3] = g.n_cell_entries;
+    counts8[4] = g.n_always; counts8[5] = g.n_entries; counts8[6] = g.max_groups; counts8[7] = g.nonempty;
+  }
+  if (geom12)
+    for (int k = 0; k < 3; k++) { geom12[k] = g.lo[k]; geom12[3 + k] = g.h[k]; geom12[6 + k] = g.hi[k]; geom12[9 + k] = g.c0[k]; }
+  if (margin4) { margin4[0] = g.s0; margin4[1] = g.rmin; margin4[2] = g.rmax; margin4[3] = g.d_near; }
+  if (delta_g) *delta_g = g.delta_g;
+  if ((cells && n_cells < g.cells.size()) || (entries && entry_floats < g.entries.size()) ||
+      (entry_index && n_index < g.entry_index.size()))
+    return PT_ERR_CAPACITY;
+  if (cells) std::copy(g.cells.begin(), g.cells.end(), cells);
+  if (entries) std::copy(g.entries.begin(), g.entries.end(), entries);
+  if (entry_index) std::copy(g.entry_index.begin(), g.entry_index.end(), entry_index);
+  return PT_OK;
+}
+
 PT_API int pt_build_bvh(const PtSphere* s, uint32_t n, float* nodes, size_t node_floats, float* slots,
                         size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
                         uint32_t* counts5, uint32_t* nodes16, size_t n_words16, float* kscale,

@@ -51,17 +51,25 @@ struct PtKernelArgs {
   const float* geom;          // PT_LDS_ENTRIES(n_spheres) * {cx, cy, cz, r*r}, padded with unreachable spheres
   const PtMatRec* mat;        // n_spheres
   float* slab;                // n_passes * local_rows * width * float4 (rgb sum, spp)
-  unsigned long long* counters;  // [0] work-queue head, [1] segments, [2] samples
+  unsigned long long* counters;  // [0] work-queue head, [1] segments; [8..15] executed-work tallies of the COUNT twins
   const uint32_t* tile_order;    // n_tiles: queue position -> tile (heaviest tiles first)
   uint32_t* tile_cost;           // n_tiles: longest item (segments) per tile, feeds the next launch's order
-  unsigned long long* timeline;  // dev builds (-DPT_TIMELINE) only: 8 u64 per wave; NULL otherwise
-  // culling hierarchy of the PT_GEOM_BVH kernels (pt_bvh.hpp); unused (NULL / 0) by the others
+  // culling structure of the walk kernels (pt_bvh.hpp / pt_grid.hpp); unused (NULL / 0) by the others
   const uint32_t* bvh_nodes;       // (n_nodes + 1) x 16 B: six binary16 box coordinates, skip | leaf << 16
   const float* bvh_nodes32;        // (n_nodes + 1) x 32 B: {lo - c0, skip, hi - c0, leaf}, fp32 (small scenes)
-  const float* bvh_slots;          // n_slots x {cx, cy, cz, r*r}: leaves (4 slots each), then the outliers
+  const float* bvh_slots;          // n_slots x {cx, cy, cz, r*r}: leaves / cell groups (4 slots each), then the
+                                   // spheres tested for every ray (padded to 4)
   const uint32_t* bvh_slot_index;  // n_slots: original sphere index of a slot
   uint32_t n_nodes, n_tree_slots, n_slots, n_outliers;
-  float bvh_c0[3], bvh_s0;         // per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6
+  float bvh_c0[3], bvh_s0;         // hierarchy: per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6; grid: D = |o - c0| + s0
+  // uniform grid (PT_GEOM_GRID)
+  const uint32_t* grid_cells;      // n_cells records (padded to 16 B): first group | groups << 24
+  uint32_t n_cells;
+  uint32_t grid_n[3];
+  float grid_lo[3], grid_hi[3], grid_h[3], grid_inv_h[3];
+  float grid_d_near;               // rays with |o - c0| + s0 <= d_near walk the cells
+  uint32_t lds_scene_bytes;        // dynamic LDS taken by the staged scene; the parked path state follows
+  uint32_t carry_lanes;            // the walk moves on when fewer lanes than this (and less than half) still walk
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
   uint32_t block_threads;          // blockDim.x of the launch
   uint32_t queue_chunk;            // work items a wave reserves per global-queue atomic
@@ -70,7 +78,7 @@ struct PtKernelArgs {
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
 };
 
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 64 };
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_COUNT = 64 };
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
@@ -80,6 +88,7 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_COUNT = 
 #define PT_PARK_STRIDE 15u  // dwords per lane in the parking area (odd: conflict-free columns)
 #define PT_BVH_LDS_BYTES32(n_nodes, n_slots) ((((size_t)(n_nodes) + 1u) * 2u + (size_t)(n_slots)) * 16u)
 #define PT_BVH_LDS_BYTES16(n_nodes) (((size_t)(n_nodes) + 1u) * 16u)
+#define PT_GRID_LDS_CELLS(n_cells) ((((size_t)(n_cells) + 3u) / 4u) * 16u)
 #define PT_MAX_SPHERES 65528u      // candidate queues hold 16-bit indices; beyond the LDS list the
                                    // scan reads the padded global copy (pt_trace_kernel_gmem)
 

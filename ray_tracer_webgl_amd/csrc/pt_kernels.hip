@@ -168,17 +168,26 @@ using namespace ptd;
 // HAVE_LDS   : an LDS copy of the list exists (n <= 10 232) and serves every PER-LANE indexed
 //              read (exact phase, tail mode, shading) whichever way the scan reads; without it
 //              (lists beyond the 160 KiB LDS) those gathers go to global memory.
-// BVH_MODE   : 0 = none of this.  Otherwise PHASE 1 walks the culling hierarchy of pt_bvh.hpp
-//              instead of the whole list (see the note at the traversal): 1 = nodes and slots
-//              staged in LDS, 2 = nodes in LDS, slots in global memory / L2, 3 = both in global
-//              memory.  List-order reads (tail mode, PHASE 3, shading) go to the global copy.
-template <bool SCAN_LDS, bool HAVE_LDS, int BVH_MODE = 0>
+// WALK       : 0 = PHASE 1 scans the whole list.  Otherwise PHASE 1 walks a culling structure
+//              that only decides which spheres are LOOKED AT (see the notes at the walks):
+//                1..3  the hierarchy of pt_bvh.hpp: 1 = nodes and slots staged in LDS, 2 = nodes
+//                      in LDS, slots in global memory / L2, 3 = both in global memory;
+//                4..6  the uniform grid of pt_grid.hpp: 4 = cells and entries staged in LDS,
+//                      5 = cells in LDS, entries in global memory / L2, 6 = both global.
+//              List-order reads (tail mode, PHASE 3, shading) go to the global copy.
+// COUNT      : tally what the walk executes (iterations and active lanes per phase) into
+//              A.counters — the measuring twin of a kernel, never the one that is timed.
+template <bool SCAN_LDS, bool HAVE_LDS, int WALK = 0, bool COUNT = false>
 __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
-  constexpr bool BVH = BVH_MODE != 0;
-  constexpr bool NODES_LDS = BVH_MODE == 1 || BVH_MODE == 2;
-  constexpr bool SLOTS_LDS = BVH_MODE == 1;
+  constexpr bool BVH = WALK >= 1 && WALK <= 3;
+  constexpr bool GRID = WALK >= 4;
+  constexpr bool TREE = BVH || GRID;  // a culling structure: hits are (slot, value) pairs
+  constexpr int BVH_MODE = BVH ? WALK : 0;
+  constexpr bool NODES_LDS = WALK == 1 || WALK == 2;
+  constexpr bool CELLS_LDS = WALK == 4 || WALK == 5;
+  constexpr bool SLOTS_LDS = WALK == 1 || WALK == 4;
   static_assert(HAVE_LDS || !SCAN_LDS, "an LDS scan needs the LDS copy");
-  static_assert(!BVH || (!SCAN_LDS && !HAVE_LDS), "the hierarchy kernels read list-order data from global memory");
+  static_assert(!TREE || (!SCAN_LDS && !HAVE_LDS), "the walk kernels read list-order data from global memory");
   extern __shared__ float4 s_geom[];
   const float4* __restrict__ g_geom = reinterpret_cast<const float4*>(A.geom);
   const uint4* __restrict__ g_nodes = reinterpret_cast<const uint4*>(A.bvh_nodes);
@@ -186,12 +195,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   const float4* __restrict__ g_slots = reinterpret_cast<const float4*>(A.bvh_slots);
 
   // ---- copy the (already padded, {cx,cy,cz,r*r}) geometry into LDS once per workgroup --------
-  if constexpr (HAVE_LDS && !BVH) {
+  if constexpr (HAVE_LDS && !TREE) {
     const uint32_t n_padded = PT_LDS_ENTRIES(A.n_spheres);
     for (uint32_t i = threadIdx.x; i < n_padded; i += blockDim.x) s_geom[i] = g_geom[i];
     __syncthreads();
   }
-  if constexpr (BVH_MODE == 1) { // [2 * (n_nodes + 1) halves of fp32 nodes][n_slots slots]
+  if constexpr (WALK == 1) { // [2 * (n_nodes + 1) halves of fp32 nodes][n_slots slots]
     const uint32_t n_a = 2u * (A.n_nodes + 1u);
     typedef float4 __attribute__((address_space(3))) lds_f4s;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_f4s*)s_geom;
@@ -203,10 +212,19 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     for (uint32_t i = threadIdx.x; i < A.n_slots; i += blockDim.x) s_geom[n_a + i] = g_slots[i];
     __syncthreads();
   }
-  if constexpr (BVH_MODE == 2) { // [n_nodes + 1 packed nodes]
+  if constexpr (WALK == 2) { // [n_nodes + 1 packed nodes]
     const uint32_t n_a = A.n_nodes + 1u;
     uint4* s_nodes = reinterpret_cast<uint4*>(s_geom);
     for (uint32_t i = threadIdx.x; i < n_a; i += blockDim.x) s_nodes[i] = g_nodes[i];
+    __syncthreads();
+  }
+  if constexpr (CELLS_LDS) { // [n_cells cell records, padded to 16 B][mode 4: n_slots entries]
+    const uint32_t n_c4 = (A.n_cells + 3u) >> 2;
+    const uint4* g_c4 = reinterpret_cast<const uint4*>(A.grid_cells); // the array is padded to 16 B
+    uint4* s_c4 = reinterpret_cast<uint4*>(s_geom);
+    for (uint32_t i = threadIdx.x; i < n_c4; i += blockDim.x) s_c4[i] = g_c4[i];
+    if constexpr (WALK == 4)
+      for (uint32_t i = threadIdx.x; i < A.n_slots; i += blockDim.x) s_geom[n_c4 + i] = g_slots[i];
     __syncthreads();
   }
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -223,29 +241,33 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   };
   // per-lane index (exact phase, tail mode, shading)
   auto geom_at = [&](uint32_t i) -> float4 {
-    if constexpr (HAVE_LDS && !BVH) {
+    if constexpr (HAVE_LDS && !TREE) {
       return s_geom[i];
     } else {
       return g_geom[i];
     }
   };
-  // hierarchy reads (per-lane index)
+  // culling-structure reads (per-lane index)
   auto node_at = [&](uint32_t i) -> uint4 { // packed nodes (modes 2, 3)
     if constexpr (NODES_LDS) return reinterpret_cast<const uint4*>(s_geom)[i];
     else return g_nodes[i];
   };
   auto slot_at = [&](uint32_t i) -> float4 {
-    if constexpr (SLOTS_LDS) return s_geom[2u * (A.n_nodes + 1u) + i];
+    if constexpr (WALK == 1) return s_geom[2u * (A.n_nodes + 1u) + i];
+    else if constexpr (WALK == 4) return s_geom[((A.n_cells + 3u) >> 2) + i];
     else return g_slots[i];
   };
+  auto cell_at = [&](uint32_t i) -> uint32_t {
+    if constexpr (CELLS_LDS) return reinterpret_cast<const uint32_t*>(s_geom)[i];
+    else return A.grid_cells[i];
+  };
+  (void)node_at; (void)cell_at; (void)SLOTS_LDS;
   const_f4v* c_slots = (const_f4v*)A.bvh_slots;
   // LDS behind the staged scene: PT_PARK_STRIDE dwords per lane for the parked path state.  The
   // stride is odd, so the 32 lanes of a half-wave hit 32 different banks at any fixed field, and
   // every field is an immediate offset from the lane's base address.
   typedef volatile uint32_t __attribute__((address_space(3))) lds_u32;
-  lds_u32* park = (lds_u32*)reinterpret_cast<uint32_t*>(s_geom) +
-                  4u * (BVH_MODE == 1 ? 2u * (A.n_nodes + 1u) + A.n_slots : (BVH_MODE == 2 ? A.n_nodes + 1u : 0u)) +
-                  PT_PARK_STRIDE * threadIdx.x;
+  lds_u32* park = (lds_u32*)reinterpret_cast<uint32_t*>(s_geom) + (A.lds_scene_bytes >> 2) + PT_PARK_STRIDE * threadIdx.x;
 
   // (recomputed where needed rather than kept in a VGPR for the kernel's lifetime)
 #define lane (threadIdx.x & 63u)
@@ -271,20 +293,32 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
   uint32_t seg_count = 0; // wave-uniform tally (samples are derived on the host: pixels * spp * passes)
   uint32_t pool_next = 0, pool_end = 0;     // wave-uniform: this wave's reserved queue items
-#ifdef PT_TIMELINE
-  unsigned long long tl_start = __builtin_amdgcn_s_memrealtime(), tl_dry = 0, tl_coop = 0;
-  uint32_t tl_iters = 0, tl_coop_iters = 0, tl_dry_iters = 0;
-  unsigned long long tl_p3_entries = 0, tl_p3_spheres = 0, tl_p2_iters = 0, tl_ovf_lanes = 0;
-  // wall time per phase of the main loop (100 MHz ticks): [0] refill + camera rays, [1] set-up +
-  // outliers, [2] node loops, [3] leaf loops, [4] final drain, [5] shading, [6] tail mode
-  unsigned long long tl_ph[7] = {0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tl_act[20] = {0}, tl_cnt[20] = {0};
-  uint32_t tl_step_iter = 0;
-  unsigned long long tl_mark = __builtin_amdgcn_s_memrealtime();
-#define PT_PHASE(k) do { unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tl_ph[k] += now_ - tl_mark; tl_mark = now_; } while (0)
-#else
-#define PT_PHASE(k) do { } while (0)
-#endif
+
+  // ---- walk state that survives a wave step (walk kernels) ------------------------------------
+  // The 64 walks of a wave step differ in length, and every loop runs for its longest lane:
+  // after the bulk has finished, a handful of stragglers (config 2: ~5 lanes for the last third
+  // of the node iterations) would keep the whole wave walking.  Instead, once fewer than
+  // A.carry_lanes lanes (and less than half of the wave's live lanes) are still walking, the
+  // wave moves on: the finished lanes are shaded and get their next ray, the stragglers are
+  // CARRIED — they keep their walk state in registers, skip shading, and continue their walk
+  // in the next wave step beside the fresh walks.  Results cannot change (each lane performs
+  // the same operations on the same ray, only later); segments are counted when shaded.
+  bool carried = false;
+  float closest_w = PT_MAX_T;
+  uint32_t hit_pos = 0xffffffffu; // the slot of the closest hit (its sphere index is looked up once, at the end)
+  // hierarchy: cursor, queued leaves (8 x 16 bit), queued candidates (8 x 16 bit)
+  uint32_t cur = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_cnt = 0;
+  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q_cnt = 0;
+  // grid: boundary-crossing times, linear cell index, steps left per axis (3 x 10 bit, +1),
+  // the cell being tested (first group | groups << 24), its exit time
+  float tmx = 0.f, tmy = 0.f, tmz = 0.f, t_exit = 0.f;
+  uint32_t cell = 0, rem = 0, pend = 0;
+  bool gactive = false;
+
+  // executed-work tallies of the COUNT twin (wave-uniform)
+  uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
+           n_carried = 0;
+#define PT_COUNT(IT, LN, MASK) do { if constexpr (COUNT) { IT++; LN += (uint32_t)__popcll(MASK); } } while (0)
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
   auto start_sample = [&]() {
@@ -340,9 +374,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         uint32_t item = pool_base + rank;
         uint32_t per_tile = 64u * A.n_passes;
         uint32_t tile_pos = div_(item, A.div_per_tile);
-        uint32_t rem = item - tile_pos * per_tile;
+        uint32_t rem_i = item - tile_pos * per_tile;
         uint32_t tile = A.tile_order[tile_pos]; // heaviest tiles are dealt first
-        uint32_t pass = rem >> 6, l = rem & 63u;
+        uint32_t pass = rem_i >> 6, l = rem_i & 63u;
         uint32_t ty = div_(tile, A.div_tiles_x), tx = tile - ty * A.tiles_x;
         uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
         if (px < A.width && ly < A.local_rows) {
@@ -380,8 +414,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
     unsigned long long live = pt_ballot(alive);
     if (live == 0ull) break; // every lane is exhausted: the queue is dry
-    PT_PHASE(0);
-    seg_count += (uint32_t)__popcll(live);
+    if constexpr (COUNT) n_steps++;
 
     // ---- hit_world: static/shader.frag:175-196 over the LDS list -------------------------------
     //
@@ -415,8 +448,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // whose queue overflows, or an irregular scene falls back to PHASE 3: the shader's loop
     // verbatim, in ascending order, from the first sphere the queue does not cover.
     float closest = PT_MAX_T;
+    if constexpr (TREE) closest = carried ? closest_w : PT_MAX_T;
+    if (!carried) hit_pos = 0xffffffffu;
     int hit = -1;
-    uint32_t hit_pos = 0xffffffffu; // hierarchy walk: the slot of the closest hit (its sphere index is looked up once, at the end)
     const bool fast = A.scene_regular && (a > 1e-12f) && (a < 1e6f) &&
                       (__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)),
                                        __builtin_fabsf(o.z)) < 1e15f);
@@ -433,11 +467,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // sooner at no cost in total throughput (the SIMD arbitrates by priority, then age).
     if (pt_ballot(alive && item_segs > PT_LONG_ITEM_SEGMENTS) != 0ull) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
-    // The hierarchy walk is latency-bound (per-lane LDS gathers, short dependent loops), so it
-    // wants waves, i.e. few VGPRs: the part of the path state that the walk does not touch is
+    // The walks are latency-bound (per-lane LDS gathers, short dependent loops), so they
+    // want waves, i.e. few VGPRs: the part of the path state that the walk does not touch is
     // parked in LDS while it runs (14 dwords per lane, conflict-free, see `park`) and
     // fetched back for shading.  volatile: the values must not be forwarded in registers.
-    if constexpr (BVH) {
+    if constexpr (TREE) {
       lds_u32* ps = park;
       ps[0] = f2u(sum.x); ps[1] = f2u(sum.y); ps[2] = f2u(sum.z);
       ps[3] = f2u(col.x); ps[4] = f2u(col.y); ps[5] = f2u(col.z);
@@ -445,16 +479,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       ps[9] = slab_index; ps[10] = item_tile; ps[11] = item_segs;
       ps[12] = (uint32_t)sample; ps[13] = (uint32_t)depth;
     }
-#ifdef PT_TIMELINE
-    tl_iters++;
-    if (pt_ballot(exhausted) != 0ull) { if (!tl_dry) tl_dry = __builtin_amdgcn_s_memrealtime(); tl_dry_iters++; }
-#endif
-    const bool coop = (n_live <= (int)A.coop_max_live) && (pt_ballot(alive && !fast) == 0ull);
+    const bool coop = (n_live <= (int)A.coop_max_live) && (pt_ballot(alive && !fast) == 0ull) &&
+                      (pt_ballot(carried) == 0ull);
     if (coop) {
-#ifdef PT_TIMELINE
-      if (!tl_coop) tl_coop = __builtin_amdgcn_s_memrealtime();
-      tl_coop_iters++;
-#endif
       unsigned long long todo = live;
       const uint32_t last_entry = PT_LDS_ENTRIES(n_spheres) - 1u;
       while (todo != 0ull) {
@@ -505,8 +532,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
     } else {
-    uint32_t q0 = 0, q1 = 0, q2 = 0; // candidate queue, newest in the low half of q0
-    uint32_t q_cnt = 0;
     uint32_t lit_from = fast ? 0xffffffffu : 0u; // first sphere index PHASE 3 must take over
     const bool scan_lane = alive && fast;
 
@@ -544,9 +569,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // Each lane walks the tree on its own (depth-first order with skip links: next = hit ?
       // i + 1 : skip[i]); leaves are queued (8 x 16 bit) and processed in a second lockstep
       // loop so that node steps and leaf steps do not serialise against each other.
-      uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_cnt = 0;
-      uint32_t q3 = 0; // this path queues up to EIGHT candidates (q0..q3)
       const uint32_t n_nodes = A.n_nodes;
+      const bool fresh = scan_lane && !carried;
 
       auto eval_slot = [&](uint32_t pos) {
         const float4 g = slot_at(pos);
@@ -568,10 +592,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       };
       // pops and evaluates queued candidates while more than `keep` are queued (lockstep)
       auto drain_to = [&](uint32_t keep) {
-        while (pt_ballot(q_cnt > keep) != 0ull) {
-#ifdef PT_TIMELINE
-          tl_p2_iters++;
-#endif
+        for (;;) {
+          const unsigned long long m_q = pt_ballot(q_cnt > keep);
+          if (m_q == 0ull) break;
+          PT_COUNT(n_exact_it, n_exact_ln, m_q);
           if (q_cnt > keep) {
             const uint32_t pp = q0 & 0xffffu;
             q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
@@ -601,12 +625,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }                                                                             \
   }
       // the outliers: wave-uniform walk (scalar loads), as the list kernels do for every sphere
-      // (one at a time: there is usually exactly one, the ground)
+      // (one at a time: there is usually exactly one, the ground); carried lanes have done this
       for (uint32_t i = A.n_tree_slots; i < A.n_tree_slots + A.n_outliers; i++) {
         if (((i - A.n_tree_slots) & 3u) == 0u && i != A.n_tree_slots) drain_to(4u); // room for four more
         const f4v e0 = c_slots[i];
         PT_TEST(e0, hb0, cc0, ds0)
-        if (scan_lane && !(ds0 < 0.0f)) note_slot(i, hb0, cc0);
+        if (fresh && !(ds0 < 0.0f)) note_slot(i, hb0, cc0);
       }
 
       const float px = o.x - A.bvh_c0[0], py = o.y - A.bvh_c0[1], pz = o.z - A.bvh_c0[2];
@@ -630,11 +654,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       typedef float4 __attribute__((address_space(3))) lds_f4w;
       const uint32_t walk_base = BVH_MODE == 1 ? (uint32_t)(uintptr_t)(lds_f4w*)s_geom : 0u;
       const uint32_t walk_end = walk_base + n_nodes * walk_step;
-      uint32_t cur = scan_lane ? walk_base : walk_end;
-#ifdef PT_TIMELINE
-      tl_step_iter = 0;
-#endif
-      PT_PHASE(1);
+      if (!carried) cur = scan_lane ? walk_base : walk_end;
+      uint32_t walk_iters = 0;
+      bool stop = false; // wave-uniform: the stragglers are carried into the next wave step
       for (;;) {
         // Loop-carried state changes through selects only; the one real branch is the push.  A
         // lane whose walk is over rests on the spare node behind the tree (it links to itself,
@@ -643,16 +665,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         // the node's byte offset (skip links are stored scaled): no address arithmetic.
         for (;;) {
           const bool on = cur < walk_end;
-          if (pt_ballot(on) == 0ull) break;
+          const unsigned long long m_on = pt_ballot(on);
+          if (m_on == 0ull) break;
           if (pt_ballot(l_cnt == 8u) != 0ull) break;
-#ifdef PT_TIMELINE
-          tl_p3_entries++; tl_ovf_lanes += __popcll(pt_ballot(on));
-          { // active lanes by node-iteration index of this wave step (buckets of 4 iterations)
-            const uint32_t bk = tl_step_iter < 76u ? tl_step_iter >> 2 : 19u;
-            tl_act[bk] += __popcll(pt_ballot(on)); tl_cnt[bk]++;
-            tl_step_iter++;
+          {
+            const uint32_t n_on = (uint32_t)__popcll(m_on);
+            if (walk_iters >= 4u && n_on < A.carry_lanes && 2u * n_on < (uint32_t)n_live) { stop = true; break; }
           }
-#endif
+          walk_iters++;
+          PT_COUNT(n_walk_it, n_walk_ln, m_on);
           float t1x, t2x, t1y, t2y, t1z, t2z;
           uint32_t skip, leaf;
           if constexpr (BVH_MODE == 1) {
@@ -692,7 +713,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           }
           cur = through ? cur + walk_step : skip;
         }
-        PT_PHASE(2);
         // leaf phase: a lane takes a leaf only while its candidate queue (eight entries) has room
         // for the four a leaf can add; when the only leaves left belong to lanes with fuller
         // queues, those are drained and the loop resumes.  Pops are branch-free (a variable
@@ -700,10 +720,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         for (;;) {
           for (;;) {
             const bool busy = (l_cnt != 0u) & (q_cnt <= 4u);
-            if (pt_ballot(busy) == 0ull) break;
-#ifdef PT_TIMELINE
-            tl_p3_spheres++;
-#endif
+            const unsigned long long m_busy = pt_ballot(busy);
+            if (m_busy == 0ull) break;
+            PT_COUNT(n_leaf_it, n_leaf_ln, m_busy);
             const uint32_t base = (l0 & 0xffffu) << 2;
             const uint32_t sh = busy ? 16u : 0u;
             l0 = __builtin_amdgcn_alignbit(l1, l0, sh);
@@ -724,16 +743,211 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           if (pt_ballot(l_cnt != 0u) == 0ull) break;
           drain_to(4u);
         }
-        PT_PHASE(3);
-        if (pt_ballot(cur < walk_end) == 0ull) break;
+        if (stop || pt_ballot(cur < walk_end) == 0ull) break;
       }
 #undef PT_SLOT_PAIR
 
       // PHASE 2: exact evaluation of whatever is still queued
       drain_to(0u);
+      carried = cur < walk_end;
+      if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(carried));
       if (hit_pos != 0xffffffffu) hit = (int)A.bvh_slot_index[hit_pos];
-      PT_PHASE(4);
+    } else if constexpr (GRID) {
+      // PHASE 1 (uniform grid, pt_grid.hpp).  The ORDER in which spheres are looked at is free and
+      // spheres that cannot pass need not be looked at (note at PHASE 1 above).  A sphere can be
+      // hit only at a point within delta of its surface (error analysis in pt_grid.hpp), hence
+      // inside its bounding box inflated by delta; the grid registers every sphere in all cells
+      // that box touches (inflation delta_g: the bound for rays that start within d_near of the
+      // scene's middle, plus the rounding of this walk), so a ray only has to look at the
+      // entries of the cells it passes through — in order, which lets it stop as soon as the
+      // closest accepted root lies before the exit of the cell just finished (whatever is
+      // registered only in later cells has a later root).  Every entry that is looked at runs
+      // the LITERAL test; far-out giants and spheres much larger than a cell are not gridded:
+      // every ray tests them first, through scalar loads.
+      const uint32_t n_cell_entries = A.n_tree_slots;
+      const bool fresh = scan_lane && !carried;
+
+      // exact part of hit_sphere for the candidates of ONE group of four entries (4-bit mask),
+      // all lanes in lockstep: max-over-lanes(popcount) ~ 1-2 evaluations per group
+#define PT_EXACT_GROUP(BASE, MASK)                                                              \
+  for (;;) {                                                                                    \
+    const unsigned long long m_x = pt_ballot((MASK) != 0u);                                     \
+    if (m_x == 0ull) break;                                                                     \
+    PT_COUNT(n_exact_it, n_exact_ln, m_x);                                                      \
+    if ((MASK) != 0u) {                                                                         \
+      const uint32_t k = (uint32_t)__builtin_ctz(MASK);                                         \
+      MASK &= MASK - 1u;                                                                        \
+      const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));             \
+      const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));               \
+      const float sqrtd = __builtin_sqrtf(disc);                                                \
+      float v = (-half_b - sqrtd) / a;             /* :158 */                                   \
+      if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; /* :159-160 */                               \
+      const uint32_t pos = (BASE) + k;                                                          \
+      /* order-free acceptance: smaller root wins, equal roots go to the LATER sphere of the   \
+         list; indices are only looked up for the rare exact tie (a sphere registered in two   \
+         cells meets ITSELF again: same index, no change) */                                    \
+      bool wins = v < closest;                                                                  \
+      if (v == closest)                                                                         \
+        wins = hit_pos == 0xffffffffu || A.bvh_slot_index[pos] > A.bvh_slot_index[hit_pos];     \
+      if (!(v < PT_MIN_T) && wins) {                                                            \
+        closest = v;                                                                            \
+        hit_pos = pos;                                                                          \
+      }                                                                                         \
+    }                                                                                           \
+  }
+#define PT_PASSES(HB, CC, DS) (!((DS) < 0.0f) && !((CC) > 0.0f && (HB) >= 0.0f))
+
+      // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is
+      // padded with entries that never pass); carried lanes have done this
+      {
+        const uint32_t n_grp = (A.n_outliers + 3u) >> 2;
+        for (uint32_t gi = 0; gi < n_grp; gi++) {
+          const uint32_t base = n_cell_entries + 4u * gi;
+          const f4v e0 = c_slots[base], e1 = c_slots[base + 1u], e2 = c_slots[base + 2u], e3 = c_slots[base + 3u];
+          PT_TEST(e0, hb0, cc0, ds0)
+          PT_TEST(e1, hb1, cc1, ds1)
+          PT_TEST(e2, hb2, cc2, ds2)
+          PT_TEST(e3, hb3, cc3, ds3)
+          uint32_t mask = 0u;
+          if (fresh)
+            mask = (PT_PASSES(hb0, cc0, ds0) ? 1u : 0u) | (PT_PASSES(hb1, cc1, ds1) ? 2u : 0u) |
+                   (PT_PASSES(hb2, cc2, ds2) ? 4u : 0u) | (PT_PASSES(hb3, cc3, ds3) ? 8u : 0u);
+          PT_EXACT_GROUP(base, mask)
+        }
+      }
+
+      // per-ray constants of the walk (recomputed for carried lanes: cheaper than keeping them)
+      const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f);
+      const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f);
+      const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f);
+      const bool posx = ix > 0.0f, posy = iy > 0.0f, posz = iz > 0.0f;
+      const float tdx = A.grid_h[0] * __builtin_fabsf(ix), tdy = A.grid_h[1] * __builtin_fabsf(iy),
+                  tdz = A.grid_h[2] * __builtin_fabsf(iz);
+      const int sdx = posx ? 1 : -1;
+      const int sdy = posy ? (int)A.grid_n[0] : -(int)A.grid_n[0];
+      const int sdz = posz ? (int)(A.grid_n[0] * A.grid_n[1]) : -(int)(A.grid_n[0] * A.grid_n[1]);
+
+      // entry: where does the half-line meet the grid's box?
+      if (!carried) { gactive = false; pend = 0u; }
+      if (pt_ballot(fresh) != 0ull) {
+        const float px = o.x - A.bvh_c0[0], py = o.y - A.bvh_c0[1], pz = o.z - A.bvh_c0[2];
+        // D >= |o - C| for every gridded sphere; v_sqrt_f32 is good to 1 ulp, the comparison
+        // below and the far margin carry far more slack than that
+        const float D = __builtin_amdgcn_sqrtf(fma_(pz, pz, fma_(py, py, px * px))) + A.bvh_s0;
+        const bool near = D <= A.grid_d_near * 0.9999f;
+        // near rays: every registered box lies inside [lo, hi] (delta_g is part of it).  Far rays
+        // test the box inflated by their own delta(D) <= sqrt(40 u) D + 16 u rmax < 1.7e-3 D; if
+        // they enter they take the literal loop (PHASE 3) over the whole list.  1e-6 D (plus an
+        // absolute crumb for degenerate scenes) covers the rounding of the slab arithmetic.
+        const float mm = fma_(near ? 1e-6f : 1.7e-3f, D, 1e-30f);
+        const float t1x = ((A.grid_lo[0] - mm) - o.x) * ix, t2x = ((A.grid_hi[0] + mm) - o.x) * ix;
+        const float t1y = ((A.grid_lo[1] - mm) - o.y) * iy, t2y = ((A.grid_hi[1] + mm) - o.y) * iy;
+        const float t1z = ((A.grid_lo[2] - mm) - o.z) * iz, t2z = ((A.grid_hi[2] + mm) - o.z) * iz;
+        const float tn = __builtin_fmaxf(
+            __builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+            __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+        const float tf = __builtin_fminf(
+            __builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+            __builtin_fmaxf(t1z, t2z));
+        bool enter = fresh && tn <= __builtin_fminf(tf, closest);
+        if (enter && !near) { // (rare) a ray from far away that does reach the grid
+          lit_from = 0u;
+          closest = PT_MAX_T;
+          hit_pos = 0xffffffffu;
+          enter = false;
+        }
+        if (enter) {
+          gactive = true;
+          // the cell that holds the entry point (clamped: rounding may put it a hair outside)
+          const float fx = (fma_(d.x, tn, o.x) - A.grid_lo[0]) * A.grid_inv_h[0];
+          const float fy = (fma_(d.y, tn, o.y) - A.grid_lo[1]) * A.grid_inv_h[1];
+          const float fz = (fma_(d.z, tn, o.z) - A.grid_lo[2]) * A.grid_inv_h[2];
+          const int nx1 = (int)A.grid_n[0] - 1, ny1 = (int)A.grid_n[1] - 1, nz1 = (int)A.grid_n[2] - 1;
+          int cx = (int)__builtin_floorf(fx), cy = (int)__builtin_floorf(fy), cz = (int)__builtin_floorf(fz);
+          cx = cx < 0 ? 0 : (cx > nx1 ? nx1 : cx);
+          cy = cy < 0 ? 0 : (cy > ny1 ? ny1 : cy);
+          cz = cz < 0 ? 0 : (cz > nz1 ? nz1 : cz);
+          // times at which the ray crosses the cell's far planes (the side follows the sign of
+          // the CLAMPED reciprocal, so a zero component gets a plane it never reaches: +-1e18 times
+          // a non-negative distance) — never before the entry time
+          const float bx = fma_((float)(cx + (posx ? 1 : 0)), A.grid_h[0], A.grid_lo[0]);
+          const float by = fma_((float)(cy + (posy ? 1 : 0)), A.grid_h[1], A.grid_lo[1]);
+          const float bz = fma_((float)(cz + (posz ? 1 : 0)), A.grid_h[2], A.grid_lo[2]);
+          tmx = __builtin_fmaxf((bx - o.x) * ix, tn);
+          tmy = __builtin_fmaxf((by - o.y) * iy, tn);
+          tmz = __builtin_fmaxf((bz - o.z) * iz, tn);
+          // steps left before the walk leaves the grid, + 1, three 10-bit fields
+          rem = (uint32_t)((posx ? nx1 - cx : cx) + 1) | ((uint32_t)((posy ? ny1 - cy : cy) + 1) << 10) |
+                ((uint32_t)((posz ? nz1 - cz : cz) + 1) << 20);
+          cell = ((uint32_t)cz * A.grid_n[1] + (uint32_t)cy) * A.grid_n[0] + (uint32_t)cx;
+        }
+      }
+
+      uint32_t walk_iters = 0;
+      for (;;) {
+        // advance: a lane without a cell under test looks at the cell it stands in, notes its
+        // exit time, and steps on; it leaves this loop with a non-empty cell or with its walk over
+        for (;;) {
+          const bool mv = gactive && (pend >> 24) == 0u;
+          const unsigned long long m_mv = pt_ballot(mv);
+          if (m_mv == 0ull) break;
+          PT_COUNT(n_walk_it, n_walk_ln, m_mv);
+          if (mv) {
+            const uint32_t rec = cell_at(cell);
+            const float tmin = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
+            const bool isx = tmx == tmin;
+            const bool isy = !isx && tmy == tmin;
+            const bool isz = !isx && !isy;
+            t_exit = tmin;
+            pend = rec;
+            tmx += isx ? tdx : 0.0f;
+            tmy += isy ? tdy : 0.0f;
+            tmz += isz ? tdz : 0.0f;
+            const uint32_t dec = isx ? 1u : (isy ? 1024u : 1048576u);
+            rem -= dec;
+            const bool out = (rem & (dec * 1023u)) == 0u;
+            cell += (uint32_t)(isx ? sdx : (isy ? sdy : sdz));
+            // the walk is over when it leaves the grid — or, on an empty cell, when the closest
+            // root so far lies strictly before this cell's exit (a non-empty cell asks again
+            // after its entries have been tested)
+            if (out || ((rec >> 24) == 0u && closest < tmin)) gactive = false;
+          }
+        }
+        const bool has = (pend >> 24) != 0u;
+        const unsigned long long m_has = pt_ballot(has);
+        if (m_has == 0ull) break; // no cell under test and nobody can move: every walk is over
+        PT_COUNT(n_leaf_it, n_leaf_ln, m_has);
+        {
+          // one group of four entries of the cell under test
+          const uint32_t base = (pend & 0xffffffu) << 2;
+          const float4 g0 = slot_at(base), g1 = slot_at(base + 1u), g2 = slot_at(base + 2u), g3 = slot_at(base + 3u);
+          PT_TEST(g0, hb0, cc0, ds0)
+          PT_TEST(g1, hb1, cc1, ds1)
+          PT_TEST(g2, hb2, cc2, ds2)
+          PT_TEST(g3, hb3, cc3, ds3)
+          uint32_t mask = 0u;
+          if (has) {
+            mask = (PT_PASSES(hb0, cc0, ds0) ? 1u : 0u) | (PT_PASSES(hb1, cc1, ds1) ? 2u : 0u) |
+                   (PT_PASSES(hb2, cc2, ds2) ? 4u : 0u) | (PT_PASSES(hb3, cc3, ds3) ? 8u : 0u);
+            pend = pend + 1u - (1u << 24); // next group, one fewer
+          }
+          PT_EXACT_GROUP(base, mask)
+          // the cell is done: can anything registered only in later cells still win?
+          if (has && (pend >> 24) == 0u && closest < t_exit) gactive = false;
+        }
+        walk_iters++;
+        const unsigned long long m_on = pt_ballot(gactive || (pend >> 24) != 0u);
+        if (m_on == 0ull) break;
+        const uint32_t n_on = (uint32_t)__popcll(m_on);
+        if (walk_iters >= 2u && n_on < A.carry_lanes && 2u * n_on < (uint32_t)n_live) break; // carry the stragglers
+      }
+#undef PT_EXACT_GROUP
+#undef PT_PASSES
+      carried = gactive || (pend >> 24) != 0u;
+      if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(carried));
+      if (hit_pos != 0xffffffffu) hit = (int)A.bvh_slot_index[hit_pos];
     } else {
+    uint32_t q_cnt = 0, q0 = 0, q1 = 0, q2 = 0; // candidate queue, newest in the low half of q0
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
       if (c > 0.0f && half_b >= 0.0f) return; // behind the ray: both roots <= 0
       if (q_cnt < 6u) {
@@ -788,9 +1002,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
     // PHASE 2: exact evaluation of the queued candidates, newest (largest index) first
     while (pt_ballot(q_cnt != 0u) != 0ull) {
-#ifdef PT_TIMELINE
-      tl_p2_iters++;
-#endif
       if (q_cnt != 0u) {
         const uint32_t idx = q0 & 0xffffu;
         q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
@@ -810,7 +1021,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
     }
-    } // !BVH
+    } // list scan
 
     // PHASE 3: the shader's loop verbatim for whatever the queue does not cover (rare)
     {
@@ -825,9 +1036,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           start = other < start ? other : start;
         }
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-#ifdef PT_TIMELINE
-        tl_p3_entries++; tl_p3_spheres += n_spheres - start; tl_ovf_lanes += __popcll(lit_mask);
-#endif
         for (uint32_t i = start; i < n_spheres; i++) {
           const float4 g = geom_scan(i);
           PT_TEST(g, half_b, c, disc)
@@ -850,9 +1058,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
     } // !coop
 #undef PT_TEST
-    if (coop) { PT_PHASE(6); }
+    if constexpr (TREE) {
+      if (coop) carried = false;
+      closest_w = closest;
+    }
 
-    if constexpr (BVH) {
+    if constexpr (TREE) {
       lds_u32* ps = park;
       sum = mk(u2f(ps[0]), u2f(ps[1]), u2f(ps[2]));
       col = mk(u2f(ps[3]), u2f(ps[4]), u2f(ps[5]));
@@ -861,8 +1072,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       sample = (int)ps[12]; depth = (int)ps[13];
     }
 
-    // ---- shade: static/shader.frag:304-335 ------------------------------------------------------
-    if (alive) {
+    // ---- shade: static/shader.frag:304-335 (carried lanes are not there yet) --------------------
+    const bool shade = alive && !carried;
+    seg_count += (uint32_t)__popcll(pt_ballot(shade));
+    if (shade) {
       item_segs++;
       bool finished = false; // this camera path is over
       if (hit < 0) {
@@ -878,7 +1091,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         finished = true;
       } else {
         float4 g;
-        if constexpr (BVH) { // the walk's hits come with their slot (same four floats as the list entry)
+        if constexpr (TREE) { // the walk's hits come with their slot (same four floats as the list entry)
           if (hit_pos != 0xffffffffu) g = slot_at(hit_pos);
           else g = geom_at((uint32_t)hit);
         } else {
@@ -965,34 +1178,33 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
           reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
           if (item_tile != 0xffffffffu) atomicMax(&A.tile_cost[item_tile], item_segs);
-#ifdef PT_TIMELINE
-          { // histogram of item lengths (segments): > 384, 768, 1536, 2304, 3000
-            const uint32_t b = (item_segs > 384u) + (item_segs > 768u) + (item_segs > 1536u) + (item_segs > 2304u) + (item_segs > 3000u);
-            if (b) atomicAdd(&A.counters[15 + b], 1ull);
-          }
-#endif
           alive = false;
         } else {
           new_path = true;
         }
       }
     }
-    PT_PHASE(5);
   }
 
   if (lane == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
-#ifdef PT_TIMELINE
-  if (lane == 0 && A.timeline) {
-    unsigned long long* t = A.timeline + 8ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    t[0] = tl_start; t[1] = tl_dry; t[2] = tl_coop; t[3] = __builtin_amdgcn_s_memrealtime();
-    t[4] = tl_iters; t[5] = tl_dry_iters; t[6] = tl_coop_iters; t[7] = seg_count;
-    for (int k = 0; k < 7; k++) atomicAdd(&A.counters[8 + k], tl_ph[k]);
-    for (int k = 0; k < 20; k++) { atomicAdd(&A.counters[24 + k], tl_act[k]); atomicAdd(&A.counters[44 + k], tl_cnt[k]); }
-    atomicAdd(&A.counters[4], tl_p3_entries); atomicAdd(&A.counters[5], tl_p3_spheres); atomicAdd(&A.counters[6], tl_p2_iters); atomicAdd(&A.counters[7], tl_ovf_lanes); atomicAdd(&A.counters[3], (unsigned long long)tl_iters);
+  if constexpr (COUNT) {
+    if (lane == 0) {
+      atomicAdd(&A.counters[PT_CTR_WORK + 0], (unsigned long long)n_walk_it);
+      atomicAdd(&A.counters[PT_CTR_WORK + 1], (unsigned long long)n_walk_ln);
+      atomicAdd(&A.counters[PT_CTR_WORK + 2], (unsigned long long)n_leaf_it);
+      atomicAdd(&A.counters[PT_CTR_WORK + 3], (unsigned long long)n_leaf_ln);
+      atomicAdd(&A.counters[PT_CTR_WORK + 4], (unsigned long long)n_exact_it);
+      atomicAdd(&A.counters[PT_CTR_WORK + 5], (unsigned long long)n_exact_ln);
+      atomicAdd(&A.counters[PT_CTR_WORK + 6], (unsigned long long)n_steps);
+      atomicAdd(&A.counters[PT_CTR_WORK + 7], (unsigned long long)n_carried);
+    }
   }
-#endif
+  (void)n_walk_it; (void)n_walk_ln; (void)n_leaf_it; (void)n_leaf_ln; (void)n_exact_it; (void)n_exact_ln;
+  (void)n_steps; (void)n_carried; (void)tmx; (void)tmy; (void)tmz; (void)t_exit; (void)cell; (void)rem;
+  (void)pend; (void)gactive; (void)cur; (void)l0; (void)l1; (void)l2; (void)l3; (void)l_cnt; (void)q0; (void)q1;
+  (void)q2; (void)q3; (void)q_cnt; (void)closest_w;
+#undef PT_COUNT
 #undef lane
-#undef PT_PHASE
 }
 
 // blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
@@ -1011,24 +1223,44 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(
   pt_trace_body<false, false>(A);
 }
 
-// The hierarchy kernels are latency-bound, not issue-bound: for scenes small enough that LDS
-// leaves room for them, six waves per SIMD (80 VGPRs, a handful of spills around the walk)
-// beat five with no spills (config 2: -5 %).  The kernels for larger scenes are held to four
-// waves by their LDS footprint and keep their registers.
+// The walk kernels are latency-bound, not issue-bound: for scenes small enough that LDS
+// leaves room for them, six waves per SIMD (80 VGPRs) beat five with no spills (config 2: -5 %).
+// The kernels for larger scenes are held to four waves by their LDS footprint and keep their
+// registers.
 #ifndef PT_BVH_WAVES
 #define PT_BVH_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
 // the hierarchy walk (PT_GEOM_BVH): nodes + slots staged in LDS (dynamic LDS =
-// PT_BVH_LDS_BYTES(n_nodes, n_slots)), or read from global memory / L2 when they do not fit
+// PT_BVH_LDS_BYTES32(n_nodes, n_slots) + parking), or read from global memory / L2 when they do not fit
 extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh(const PtKernelArgs A) {
   pt_trace_body<false, false, 1>(A);
 }
-// nodes staged (dynamic LDS = (n_nodes + 1) * 16 bytes), slots read from global memory
+// nodes staged (dynamic LDS = (n_nodes + 1) * 16 bytes + parking), slots read from global memory
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_nodes(const PtKernelArgs A) {
   pt_trace_body<false, false, 2>(A);
 }
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem(const PtKernelArgs A) {
   pt_trace_body<false, false, 3>(A);
+}
+// the grid walk (PT_GEOM_GRID): cells + entries staged in LDS, cells only, or nothing
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid(const PtKernelArgs A) {
+  pt_trace_body<false, false, 4>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells(const PtKernelArgs A) {
+  pt_trace_body<false, false, 5>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem(const PtKernelArgs A) {
+  pt_trace_body<false, false, 6>(A);
+}
+// measuring twins (PT_OPT_COUNT_WORK): the same walks with the executed-work tallies
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh_count(const PtKernelArgs A) {
+  pt_trace_body<false, false, 1, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_count(const PtKernelArgs A) {
+  pt_trace_body<false, false, 4, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells_count(const PtKernelArgs A) {
+  pt_trace_body<false, false, 5, true>(A);
 }
 
 // --------------------------------------------------------------------------------------------

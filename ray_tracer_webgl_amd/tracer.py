@@ -95,8 +95,18 @@ class PathTracer:
 
     def set_geometry_path(self, path):
         """abi.PT_GEOM_AUTO (default: measure the usable paths once per scene) / PT_GEOM_LDS /
-        PT_GEOM_SCALAR / PT_GEOM_BVH."""
+        PT_GEOM_SCALAR / PT_GEOM_BVH / PT_GEOM_GRID."""
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_GEOMETRY_PATH, int(path)))
+
+    def set_count_work(self, on=True):
+        """Walk kernels: launch the measuring twin, which fills stats().work (executed iterations
+        and active lanes per phase).  Slower; never time it."""
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_COUNT_WORK, 1 if on else 0))
+
+    def set_carry_lanes(self, n):
+        """Walk kernels: move on to shading when fewer than n lanes (and less than half the wave)
+        still walk; 0 = lockstep.  Scheduling only: images do not depend on it."""
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_CARRY_LANES, int(n)))
 
     def tune(self, n_passes):
         """Settle PT_GEOM_AUTO now (one cold + one untimed launch of n_passes passes per usable

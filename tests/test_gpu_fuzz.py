@@ -100,6 +100,73 @@ def test_random_scenes_bit_exact_through_the_hierarchy(ora, seed):
     t.close()
 
 
+GRID_USED = []
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scenes_bit_exact_through_the_grid(ora, seed):
+    """The same kind of scenes with the grid walk forced: whatever the walk does not look at —
+    spheres registered only in cells it never enters, or only in cells behind its early exit —
+    must be something the shader's loop would not have returned.  Duplicates and concentric
+    spheres are entries of the same cells (ties go to the later list index whatever the entry
+    order); big spheres are copied into many cells or tested for every ray."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500]))
+    width, height = int(rng.integers(9, 150)), int(rng.integers(5, 90))
+    if n >= 400:
+        width, height = min(width, 64), min(height, 40)
+    spp, depth, passes = int(rng.integers(1, 9)), int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 4))
+    sc = random_scene(rng, n, width, height, spp, depth, passes)
+    if seed % 3 != 1:  # mostly small spheres, spread out: what a grid is for
+        small = rng.random(n) < 0.9
+        sc.spheres["radius"][small] = (np.sign(sc.spheres["radius"][small]) * rng.uniform(0.05, 0.4, small.sum())).astype(np.float32)
+        sc.spheres["center"] *= np.float32(rng.choice([2.0, 6.0, 20.0]))
+    if seed % 4 == 0:  # a flat field: one layer of cells
+        sc.spheres["center"][:, 1] = np.float32(0.3)
+    t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=abi.PT_GEOM_GRID)
+    ref, seg = ora.render(sc.spheres, sc.params, passes)
+    g, r = bits(got), bits(ref)
+    st = t.stats()
+    assert np.array_equal(g, r), "seed %d (path %d): %d of %d values differ" % (seed, st.geometry_path, (g != r).sum(), g.size)
+    assert st.segments == seg
+    # a scene the grid cannot represent falls back to the hierarchy; most of these get a grid
+    assert st.geometry_path in (abi.PT_GEOM_GRID, abi.PT_GEOM_BVH)
+    GRID_USED.append(st.geometry_path == abi.PT_GEOM_GRID)
+    t.close()
+
+
+def test_the_grid_fuzz_did_run_through_the_grid():
+    assert len(GRID_USED) == 48 and sum(GRID_USED) >= 36, GRID_USED
+
+
+def test_tie_break_order_matters_in_the_grid(ora):
+    """Two coincident spheres far apart in the list, among filler: both are entries of the same
+    cells, in an order that has nothing to do with the list order, and the LATER list entry must
+    still win — also when one copy is met in one cell and the other in the next."""
+    base = scenes.config1(120, 72, 4, 8)
+    a = base.spheres[1:2].copy()
+    b = a.copy()
+    b["albedo"] = (0.1, 0.9, 0.1)
+    rng = np.random.default_rng(7)
+    filler = np.zeros(40, dtype=abi.SPHERE_DTYPE)
+    filler["center"] = rng.uniform(-6, 6, (40, 3)) * (1.0, 0.2, 1.0) + (0, 0.5, -6)
+    filler["radius"] = 0.3
+    filler["albedo"] = 0.6
+    imgs = []
+    for order in ((a, b), (b, a)):
+        sc = scenes.config1(120, 72, 4, 8)
+        sc.spheres = np.concatenate([base.spheres[:1], order[0], filler[:11], base.spheres[2:], filler[11:], order[1]])
+        sc.spheres["uuid"] = np.arange(len(sc.spheres))
+        sc.n_passes = 2
+        t, got = render_scene(sc, geometry_path=abi.PT_GEOM_GRID)
+        ref, seg = ora.render(sc.spheres, sc.params, 2)
+        assert np.array_equal(bits(got), bits(ref)) and t.stats().segments == seg
+        assert t.stats().geometry_path == abi.PT_GEOM_GRID
+        imgs.append(got)
+        t.close()
+    assert not np.array_equal(imgs[0], imgs[1])
+
+
 def test_tie_break_order_matters_in_the_hierarchy(ora):
     """As below, with enough filler spheres for a tree: the two coincident spheres land in tree
     slots whose order has nothing to do with the list order, and the LATER list entry must

@@ -643,28 +643,28 @@ def test_sphere_list_beyond_lds_capacity(ora):
     t.close()
 
 
-@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH, abi.PT_GEOM_AUTO])
+@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH, abi.PT_GEOM_GRID, abi.PT_GEOM_AUTO])
 def test_geometry_paths_are_bit_identical(ora, path):
-    """LDS walk, scalar-load walk, hierarchy walk and the autotuned choice give the same bits
-    (and the same segment counts) on scenes that exercise every phase of hit_world."""
+    """LDS walk, scalar-load walk, hierarchy walk, grid walk and the autotuned choice give the same
+    bits (and the same segment counts) on scenes that exercise every phase of hit_world."""
     for sc in (scenes.default_scene(96, 54, spp=4, max_depth=8), scenes.config2(96, 54, 4, 2, 50),
                scenes.config4(48, 48, 4, 2, 50)):
-        sc.n_passes = 5
-        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 5 launches: AUTO tries them all
-        ref, seg = ora.render(sc.spheres, sc.params, 5)
+        sc.n_passes = 6
+        t, got = render_scene(sc, passes_per_launch=1, geometry_path=path)  # 6 launches: AUTO tries them all
+        ref, seg = ora.render(sc.spheres, sc.params, 6)
         assert_bit_equal(got, ref, "%s path %d" % (sc.name, path))
         st = t.stats()
         assert st.segments == seg
         has_tree = len(sc.spheres) >= 16
-        assert (st.bvh_nodes > 0) == has_tree
-        if path == abi.PT_GEOM_BVH:
-            # scenes without a hierarchy (fewer than 16 spheres) fall back to the scalar walk
-            assert st.geometry_path == (abi.PT_GEOM_BVH if has_tree else abi.PT_GEOM_SCALAR)
+        assert (st.bvh_nodes > 0) == has_tree and (st.grid_entries > 0) == has_tree
+        if path in (abi.PT_GEOM_BVH, abi.PT_GEOM_GRID):
+            # scenes without a culling structure (fewer than 16 spheres) fall back to the scalar walk
+            assert st.geometry_path == (path if has_tree else abi.PT_GEOM_SCALAR)
         elif path != abi.PT_GEOM_AUTO:
             assert st.geometry_path == path
         else:
             assert st.geometry_tuned == 1
-            assert st.geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR) + ((abi.PT_GEOM_BVH,) if has_tree else ())
+            assert st.geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR) + ((abi.PT_GEOM_BVH, abi.PT_GEOM_GRID) if has_tree else ())
         t.close()
     assert t.lib.pt_set_option(None, 1, 1) == abi.PT_ERR_INVALID
 
@@ -681,6 +681,55 @@ def test_hierarchy_in_global_memory(ora):
     assert t2.stats().segments == st.segments
     t.close()
     t2.close()
+
+
+def test_grid_kernels_for_scenes_beyond_the_lds(ora):
+    """10 001 spheres: the cell records fit the LDS, the entries (0.7 MB) do not:
+    pt_trace_kernel_grid_cells gathers them from global memory / L2.  Window-checked against the
+    oracle, whole frame against the list walk; then the measuring twin of the same kernel."""
+    sc = scenes.config5(160, 90, 2, 1, 20)
+    t, got, ref = _check_scene(ora, sc, window=(60, 84, 30, 46), geometry_path=abi.PT_GEOM_GRID)
+    st = t.stats()
+    assert st.geometry_path == abi.PT_GEOM_GRID and st.grid_entries * 16 > 160 * 1024
+    assert st.grid_cells[0] * st.grid_cells[1] * st.grid_cells[2] * 4 < 100 * 1024
+    t2, got2 = render_scene(sc, geometry_path=abi.PT_GEOM_SCALAR)
+    assert_bit_equal(got, got2, "grid walk vs list walk, whole frame")
+    assert t2.stats().segments == st.segments
+    t.reset()
+    t.set_count_work(True)
+    t.render_passes(1)
+    assert_bit_equal(t.accum(), got, "measuring twin")
+    w = t.stats().work
+    assert w[0] > 0 and w[1] >= w[0] and w[2] > 0 and w[4] > 0 and w[6] > 0
+    t.close()
+    t2.close()
+
+
+@pytest.mark.parametrize("path", [abi.PT_GEOM_BVH, abi.PT_GEOM_GRID])
+def test_carrying_stragglers_is_scheduling_only(ora, path):
+    """PT_OPT_CARRY_LANES decides when a wave stops waiting for its last walks (they continue in
+    the next wave step beside the fresh ones); images and segment counts cannot depend on it."""
+    sc = scenes.config2(160, 90, 4, 2, 50)
+    ref, seg = ora.render(sc.spheres, sc.params, 2)
+    carried = {}
+    for lanes in (0, 8, 24, 64):
+        t = PathTracer(160, 90)
+        t.set_geometry_path(path)
+        t.set_carry_lanes(lanes)
+        t.set_count_work(True)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.reserve_passes(2)
+        t.render_passes(2)
+        assert_bit_equal(t.accum(), ref, "carry_lanes %d" % lanes)
+        st = t.stats()
+        assert st.segments == seg and st.geometry_path == path
+        carried[lanes] = st.work[7]
+        t.close()
+    assert carried[0] == 0 and carried[8] > 0 and carried[24] >= carried[8]
+    t = PathTracer(8, 8)
+    assert t.lib.pt_set_option(t._ctx, abi.PT_OPT_CARRY_LANES, 65) == abi.PT_ERR_INVALID
+    t.close()
 
 
 def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):

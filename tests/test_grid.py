@@ -1,0 +1,305 @@
+"""The uniform grid of PT_GEOM_GRID (ray_tracer_webgl_amd/csrc/pt_grid.hpp), checked on the host.
+
+The grid kernels may skip a sphere only if the reference's hit_sphere (static/shader.frag:145-173)
+could not have produced the winning root, so these tests check
+  (i)   the structure pt_set_spheres uploads (registration with the inflation delta_g),
+  (ii)  the error bound the inflation rests on: the fp32 root of the literal test lies within
+        delta(D) of the sphere's surface (float64 check of float32 emulated roots),
+  (iii) a numpy emulation of the kernel's walk — same formulas, fp32, entry test, 3D-DDA, early
+        termination — against a brute-force emulation of hit_world over the whole list: the
+        walk must return the same (root, index) pair for every regular ray.
+No GPU needed: pt_build_grid is the host half of the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ray_tracer_webgl_amd import _lib, abi, scenes
+from test_bvh import SCENES, f32, fma, literal_disc, random_field, rays_for
+
+PAD = 0xFFFFFFFF
+U = 2.0 ** -24
+MIN_T = np.float32(0.001)
+MAX_T = np.float32(1e5)
+
+
+def build(spheres):
+    lib = _lib.load()
+    ptr, n, keep = abi.spheres_as_ctypes(spheres)
+    counts = np.zeros(8, np.uint32)
+    geom = np.zeros(12, np.float32)
+    margin = np.zeros(4, np.float32)
+    dg = C.c_float(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.pt_build_grid(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), None, 0, None, 0, None, 0)
+    if rc != 0:
+        return rc, None
+    nc = int(counts[0]) * int(counts[1]) * int(counts[2])
+    cells = np.zeros(nc, np.uint32)
+    entries = np.zeros((counts[5], 4), np.float32)
+    index = np.zeros(counts[5], np.uint32)
+    rc = lib.pt_build_grid(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), vp(cells), cells.size, vp(entries),
+                           entries.size, vp(index), index.size)
+    return rc, dict(n=counts[:3].astype(np.int64), n_cell_entries=int(counts[3]), n_always=int(counts[4]),
+                    n_entries=int(counts[5]), max_groups=int(counts[6]), nonempty=int(counts[7]), lo=geom[0:3], h=geom[3:6],
+                    hi=geom[6:9], c0=geom[9:12], s0=margin[0], rmin=margin[1], rmax=margin[2], d_near=margin[3],
+                    delta_g=np.float32(dg.value), cells=cells, entries=entries, index=index)
+
+
+def delta_of(rmin, rmax, D):
+    return np.sqrt(rmin * rmin + 32.0 * U * D * D) - rmin + 10.0 * U * rmax
+
+
+GRID_SCENES = dict(SCENES)
+GRID_SCENES["mixed_radii"] = lambda: np.concatenate(
+    [random_field(200, 11, extent=10.0, rmax=0.3, giants=1), random_field(6, 12, extent=8.0, rmax=4.0, giants=0)])
+GRID_SCENES["flat"] = lambda: _flat()
+
+
+def _flat():
+    s = random_field(400, 13, extent=12.0, rmax=0.25, giants=1)
+    s["center"][1:, 1] = 0.2
+    return s
+
+
+@pytest.mark.parametrize("name", sorted(GRID_SCENES))
+def test_structure(name):
+    sph = GRID_SCENES[name]()
+    rc, g = build(sph)
+    assert rc == 0
+    n = len(sph)
+    c = np.asarray(sph["center"], np.float64)
+    r = np.abs(np.asarray(sph["radius"], np.float64))
+    cells, entries, index = g["cells"], g["entries"], g["index"]
+    first, groups = (cells & 0xFFFFFF).astype(np.int64), (cells >> 24).astype(np.int64)
+    # cell records tile the gridded part of the entry array, in cell order, four entries per group
+    assert np.array_equal(first, np.concatenate([[0], np.cumsum(groups)[:-1]]))
+    assert 4 * groups.sum() == g["n_cell_entries"] and groups.max() == g["max_groups"] and (groups > 0).sum() == g["nonempty"]
+    assert g["n_entries"] % 4 == 0 and g["n_entries"] >= g["n_cell_entries"] + g["n_always"]
+    # entries are exact copies of the list records; padding can never pass the literal test
+    real = index != PAD
+    assert np.all(np.isneginf(entries[~real, 3]))
+    cs = np.asarray(sph["center"], np.float32)
+    rr = np.asarray(sph["radius"], np.float32)
+    assert np.array_equal(entries[real, :3], cs[index[real]])
+    assert np.array_equal(entries[real, 3], (rr * rr)[index[real]])
+    # every sphere is gridded or tested for every ray, never both
+    always = index[g["n_cell_entries"]:]
+    always = always[always != PAD]
+    assert len(always) == g["n_always"] and np.all(np.diff(always.astype(np.int64)) > 0)
+    gridded = np.unique(index[:g["n_cell_entries"]][index[:g["n_cell_entries"]] != PAD])
+    assert not set(gridded.tolist()) & set(always.tolist())
+    assert sorted(gridded.tolist() + always.tolist()) == list(range(n))
+    # the margin's reference data
+    c0, s0 = g["c0"].astype(np.float64), float(g["s0"])
+    reach = np.linalg.norm(c[gridded] - c0, axis=1) + r[gridded]
+    assert reach.max() <= s0 and r[gridded].min() >= g["rmin"] and r[gridded].max() <= g["rmax"]
+    assert g["d_near"] >= 3.0 * s0
+    # the registration inflation covers delta(d_near) as the KERNEL bounds it (25 % slack on E') ...
+    dk = np.sqrt(float(g["rmin"]) ** 2 + 40.0 * U * float(g["d_near"]) ** 2) - float(g["rmin"]) + 16.0 * U * float(g["rmax"])
+    assert g["delta_g"] >= dk and g["delta_g"] >= delta_of(float(g["rmin"]), float(g["rmax"]), float(g["d_near"]))
+    # ... and is not absurd next to a cell
+    assert g["delta_g"] < 0.6 * float(g["h"].min()) or name in ("clumps",)
+    # registration: a sphere is an entry of EVERY cell its box inflated by delta_g touches
+    lo, h, nn = g["lo"].astype(np.float64), g["h"].astype(np.float64), g["n"]
+    member = {}
+    for cell in np.nonzero(groups)[0]:
+        ids = index[4 * first[cell]:4 * (first[cell] + groups[cell])]
+        member[int(cell)] = set(ids[ids != PAD].tolist())
+    rng = np.random.default_rng(0)
+    for i in rng.choice(gridded, min(len(gridded), 400), replace=False):
+        a = np.clip(np.floor((c[i] - r[i] - float(g["delta_g"]) - lo) / h), 0, nn - 1).astype(np.int64)
+        b = np.clip(np.floor((c[i] + r[i] + float(g["delta_g"]) - lo) / h), 0, nn - 1).astype(np.int64)
+        for z in range(a[2], b[2] + 1):
+            for y in range(a[1], b[1] + 1):
+                for x in range(a[0], b[0] + 1):
+                    assert int(i) in member.get((z * nn[1] + y) * nn[0] + x, ()), (name, i, x, y, z)
+    # all registered boxes lie inside [lo, hi]: near rays need no inflation of the entry test
+    assert np.all(c[gridded] - r[gridded, None] - float(g["delta_g"]) >= lo - 1e-9)
+    assert np.all(c[gridded] + r[gridded, None] + float(g["delta_g"]) <= g["hi"].astype(np.float64) + 1e-9)
+    # cells of about one sphere each, a bounded number of copies
+    assert g["n_cell_entries"] <= 16 * len(gridded) + 64
+
+
+def test_giants_and_big_spheres_are_tested_for_every_ray():
+    rc, g = build(GRID_SCENES["config2"]())
+    assert rc == 0
+    always = g["index"][g["n_cell_entries"]:]
+    assert sorted(always[always != PAD].tolist()) == [0, 481, 482, 483]  # the ground and the three r = 1 spheres
+    assert g["n"][1] == 1 and g["n"][0] >= 16 and g["n"][2] >= 16             # one layer of cells over the flat field
+    assert g["s0"] < 20.0
+
+
+def test_scenes_without_a_grid():
+    assert build(scenes.default_scene(64, 36, 1, 8).spheres)[0] == abi.PT_ERR_NOT_READY  # 9 spheres
+    bad = random_field(64, 5)
+    bad["center"][7, 1] = np.inf
+    assert build(bad)[0] == abi.PT_ERR_NOT_READY
+
+
+# ---- (ii) the root of the literal test stays within delta(D) of the sphere ------------------------
+def exact_root(o, d, c, r2):
+    """candidate root of hit_sphere as the kernels evaluate it (fp32), per ray/sphere pair"""
+    oc = [f32(o[:, k] - c[:, k]) for k in range(3)]
+    hb = fma(oc[2], d[:, 2], fma(oc[1], d[:, 1], f32(oc[0] * d[:, 0])))
+    cc = fma(oc[2], oc[2], fma(oc[1], oc[1], fma(oc[0], oc[0], -r2)))
+    a = fma(d[:, 2], d[:, 2], fma(d[:, 1], d[:, 1], f32(d[:, 0] * d[:, 0])))
+    disc = fma(-a, cc, f32(hb * hb))
+    ok = ~(disc < 0) & ~((cc > 0) & (hb >= 0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sq = np.sqrt(np.where(ok, disc, 0).astype(np.float32))
+        v = f32(f32(-hb - sq) / a)
+        far = f32(f32(-hb + sq) / a)
+    v = np.where(v < MIN_T, far, v)
+    ok &= ~(v < MIN_T)
+    return v, ok
+
+
+def test_root_stays_within_delta_of_the_sphere():
+    rng = np.random.default_rng(42)
+    worst = 0.0
+    n = 200000
+    for scale in (1.0, 30.0, 1000.0):
+        r = f32(rng.choice([0.05, 0.2, 1.0, 7.0], n) * rng.uniform(0.5, 1.5, n))
+        c = f32(rng.uniform(-1, 1, (n, 3)) * scale)
+        o = f32(c + rng.normal(size=(n, 3)) * rng.choice([1.0, 3.0, 30.0], (n, 1)) * r[:, None] * rng.choice([1, 10, 100], (n, 1)))
+        # aim at the rim: where rounding decides whether and where the ray hits
+        u = rng.normal(size=(n, 3))
+        u /= np.linalg.norm(u, axis=1)[:, None]
+        target = c + u * (r * rng.choice([0.999999, 1.0, 1.000001, 0.9, 0.3], n))[:, None]
+        d = f32((target - o) * rng.choice([1.0, 0.01, 20.0], (n, 1)))
+        v, ok = exact_root(o, d, c, f32(r * r))
+        aa = np.einsum("ij,ij->i", d.astype(np.float64), d.astype(np.float64))
+        ok &= (aa > 1e-12) & (aa < 1e6)
+        P = o.astype(np.float64) + d.astype(np.float64) * v.astype(np.float64)[:, None]
+        dist = np.linalg.norm(P - c.astype(np.float64), axis=1) - r.astype(np.float64)
+        D = np.linalg.norm(o.astype(np.float64) - c.astype(np.float64), axis=1)
+        bound = np.sqrt(r.astype(np.float64) ** 2 + 32.0 * U * D * D) - r + 10.0 * U * r
+        ratio = (np.abs(dist) / bound)[ok]
+        assert ok.sum() > n // 20
+        worst = max(worst, float(ratio.max()))
+    # the analysis' constants are worst-case; the measured worst sits well inside
+    assert worst < 0.75, worst
+
+
+# ---- (iii) the kernel's walk returns hit_world's pair ---------------------------------------------
+def brute_force(o, d, sph):
+    cs = np.asarray(sph["center"], np.float32)
+    r = np.asarray(sph["radius"], np.float32)
+    disc, hb, cc = literal_disc(o, d, cs, f32(r * r))
+    a = fma(d[:, 2], d[:, 2], fma(d[:, 1], d[:, 1], f32(d[:, 0] * d[:, 0])))[:, None]
+    ok = ~(disc < 0) & ~((cc > 0) & (hb >= 0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sq = np.sqrt(np.where(ok, disc, 0).astype(np.float32))
+        v = f32(f32(-hb - sq) / a)
+        far = f32(f32(-hb + sq) / a)
+    v = np.where(v < MIN_T, far, v)
+    ok &= ~(v < MIN_T) & (v <= MAX_T)
+    v = np.where(ok, v, np.float32(np.inf))
+    best = v.min(1)
+    # ties -> the LATER sphere of the list (static/shader.frag:159)
+    idx = np.where(v == best[:, None], np.arange(v.shape[1])[None, :], -1).max(1)
+    idx = np.where(np.isinf(best), -1, idx)
+    return np.where(np.isinf(best), MAX_T, best), idx
+
+
+def walk(g, o, d, sph):
+    """pt_trace_kernel_grid's PHASE 1 (same formulas, fp32): returns closest, sphere index, and the
+    number of entries looked at per ray; far rays that enter the box take the literal loop"""
+    n = len(o)
+    ent, index = g["entries"], g["index"].astype(np.int64)
+    closest = np.full(n, MAX_T, np.float32)
+    hit = np.full(n, -1, np.int64)
+    looked = np.zeros(n, np.int64)
+
+    def test_entries(rays, pos):
+        """literal test + exact evaluation of entries `pos` (one per ray in `rays`)"""
+        nonlocal closest, hit
+        v, ok = exact_root(o[rays], d[rays], ent[pos, :3], ent[pos, 3])
+        idx = index[pos]
+        ok &= idx != PAD
+        cur, cur_hit = closest[rays], hit[rays]
+        wins = ok & ((v < cur) | ((v == cur) & ((cur_hit < 0) | (idx > cur_hit))))
+        closest[rays] = np.where(wins, v, cur)
+        hit[rays] = np.where(wins, idx, cur_hit)
+
+    allr = np.arange(n)
+    for k in range(g["n_cell_entries"], g["n_entries"]):
+        test_entries(allr, np.full(n, k))
+    with np.errstate(divide="ignore"):
+        inv = np.clip(f32(1.0) / d, f32(-1e18), f32(1e18)).astype(np.float32)
+    pos_dir = inv > 0
+    td = f32(g["h"][None, :] * np.abs(inv))
+    p = f32(o - g["c0"][None, :])
+    D = f32(np.sqrt(fma(p[:, 2], p[:, 2], fma(p[:, 1], p[:, 1], f32(p[:, 0] * p[:, 0])))) + g["s0"])
+    near = D <= f32(g["d_near"] * np.float32(0.9999))
+    mm = fma(np.where(near, np.float32(1e-6), np.float32(1.7e-3)).astype(np.float32), D, f32(np.full(n, 1e-30)))
+    t1 = f32(f32(f32(g["lo"][None, :] - mm[:, None]) - o) * inv)
+    t2 = f32(f32(f32(g["hi"][None, :] + mm[:, None]) - o) * inv)
+    tn = np.maximum(np.minimum(t1, t2).max(1), np.float32(0))
+    tf = np.maximum(t1, t2).min(1)
+    enter = tn <= np.minimum(tf, closest)
+    literal = enter & ~near
+    active = enter & near
+    nn = g["n"]
+    fcell = f32(f32(fma(d, np.broadcast_to(tn[:, None], d.shape), o) - g["lo"][None, :]) * f32(1.0 / g["h"].astype(np.float64))[None, :])
+    fcell = np.where(active[:, None], fcell, np.float32(0))  # rays that do not walk: anything finite
+    cell3 = np.clip(np.floor(fcell).astype(np.int64), 0, nn[None, :] - 1)
+    bnd = fma(f32(cell3 + pos_dir), np.broadcast_to(g["h"][None, :], d.shape), np.broadcast_to(g["lo"][None, :], d.shape))
+    tm = np.maximum(f32(f32(bnd - o) * inv), tn[:, None])
+    rem = np.where(pos_dir, nn[None, :] - 1 - cell3, cell3) + 1
+    first, groups = (g["cells"] & 0xFFFFFF).astype(np.int64), (g["cells"] >> 24).astype(np.int64)
+    for _ in range(int(nn.sum()) + 4):
+        rays = np.nonzero(active)[0]
+        if not len(rays):
+            break
+        cidx = (cell3[rays, 2] * nn[1] + cell3[rays, 1]) * nn[0] + cell3[rays, 0]
+        tmin = tm[rays].min(1)
+        isx = tm[rays, 0] == tmin
+        isy = ~isx & (tm[rays, 1] == tmin)
+        ax = np.where(isx, 0, np.where(isy, 1, 2))
+        t_exit = tmin
+        tm[rays, ax] = f32(tm[rays, ax] + td[rays, ax])
+        rem[rays, ax] -= 1
+        out = rem[rays, ax] == 0
+        cell3[rays, ax] += np.where(pos_dir[rays, ax], 1, -1)
+        # all groups of the cell
+        gmax = int(groups[cidx].max()) if len(cidx) else 0
+        for gi in range(gmax):
+            sel = groups[cidx] > gi
+            for k in range(4):
+                test_entries(rays[sel], 4 * (first[cidx[sel]] + gi) + k)
+            looked[rays[sel]] += 4
+        done = out | (closest[rays] < t_exit)
+        active[rays[done]] = False
+    return closest, hit, looked, literal
+
+
+@pytest.mark.parametrize("name", ["config2", "field300", "clumps", "field17_no_giant", "config5", "mixed_radii", "flat"])
+def test_walk_returns_the_pair_hit_world_returns(name):
+    sph = GRID_SCENES[name]()
+    rc, g = build(sph)
+    assert rc == 0
+    n_rays = 3000 if len(sph) < 2000 else 400
+    total_hits = total_looked = total_lit = 0
+    for seed in range(4):
+        o, d = rays_for(sph, n_rays, seed)
+        a = np.einsum("ij,ij->i", d.astype(np.float64), d.astype(np.float64))
+        ok = (a > 1e-12) & (a < 1e6)  # the kernel's regular rays; the others take the literal loop
+        o, d = o[ok], d[ok]
+        ref_t, ref_i = brute_force(o, d, sph)
+        got_t, got_i, looked, literal = walk(g, o, d, sph)
+        chk = ~literal  # rays from far away that enter the box run the literal loop: nothing to check
+        bad = chk & ((got_i != ref_i) | (got_t.view(np.uint32) != ref_t.view(np.uint32)))
+        assert not bad.any(), (name, seed, np.nonzero(bad)[0][:5], got_i[bad][:5], ref_i[bad][:5], got_t[bad][:5], ref_t[bad][:5])
+        total_hits += int((ref_i >= 0).sum())
+        total_looked += int(looked[chk].sum())
+        total_lit += int(literal.sum())
+    assert total_hits > 300
+    # the walk does cull: it looks at a small part of the scene per ray
+    # (`clumps` is the grid's bad case — a dense clump inside one cell of a sparse field; PT_GEOM_AUTO
+    # measures and keeps the hierarchy there)
+    if len(sph) >= 100 and name != "clumps":
+        assert total_looked < 0.2 * 4 * n_rays * len(sph)
+    assert total_lit < 0.2 * 4 * n_rays

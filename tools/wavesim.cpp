@@ -594,6 +594,7 @@ struct Sim {
   }
   void run_wave_grid() {
     Lane L[64]; GLane Gs[64]; std::vector<uint32_t> cand[64];
+    bool carried[64] = {false};
     uint64_t pn = 0, pe = 0;
     for (;;) {
       bool any_cam = false, any_refill = false; int n_cam = 0;
@@ -605,7 +606,7 @@ struct Sim {
       if (any_refill) cost += C_REFILL;
       if (any_cam) { cost += C_CAM; ph_cam.iters++; ph_cam.lanes += n_cam; }
       cost += C_SETUP_G + 2 * C_PARK + C_MISC;
-      for (int i = 0; i < 64; i++) if (L[i].alive) setup_grid(L[i], Gs[i], cand[i]); else Gs[i].active = false;
+      for (int i = 0; i < 64; i++) { if (L[i].alive) { if (!carried[i]) setup_grid(L[i], Gs[i], cand[i]); } else Gs[i].active = false; carried[i] = false; }
       // the always-tested spheres first: closest is known before the walk
       auto drain_all = [&]() {
         for (;;) {
@@ -621,6 +622,7 @@ struct Sim {
       };
       drain_all();
       for (;;) {
+        if (op.carry) { int on = 0; for (int i = 0; i < 64; i++) if (Gs[i].active || Gs[i].pend_count) on++; if (on && on < op.carry && on < live / 2) break; }
         // advance every lane to its next non-empty cell (or out)
         for (;;) {
           int mv = 0;
@@ -663,6 +665,7 @@ struct Sim {
       }
       int n = 0;
       for (int i = 0; i < 64; i++) if (L[i].alive) {
+        if (Gs[i].active || Gs[i].pend_count) { carried[i] = true; segs--; continue; }
         // shade() looks the sphere up through the tree's slot table: translate
         Lane& l = L[i];
         int sphere = l.hit_pos; int pos = -1;
