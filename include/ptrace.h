@@ -76,7 +76,7 @@ enum {
   PT_OPT_COUNT_WORK = 2,  /* 1: the walk kernels' measuring twins fill PtStats.work (slower; never time them) */
   PT_OPT_CARRY_LANES = 3, /* walk kernels: move on to shading when fewer lanes than this (and less than half
                              of the wave) are still walking; the stragglers continue in the next wave step.
-                             Scheduling only — images do not depend on it.  0 = lockstep.  Default 8. */
+                             Scheduling only — images do not depend on it.  0 = lockstep.  Default 12. */
 };
 
 /* ---- background modes ----------------------------------------------------------------------- */

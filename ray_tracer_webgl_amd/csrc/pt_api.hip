@@ -83,7 +83,7 @@ struct pt_ctx {
   size_t grid_cell_cap = 0, grid_entry_cap = 0;
   ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
   int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
-  uint32_t carry_lanes = 8;
+  uint32_t carry_lanes = 12;
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -701,7 +701,15 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
         A.grid_h[k] = g.h[k]; A.grid_inv_h[k] = g.inv_h[k];
       }
       A.bvh_s0 = g.s0;
-      A.grid_d_near = g.d_near;
+      {
+        const double rn = 0.9999 * (double)g.d_near - (double)g.s0;
+        A.grid_r2_near = ptgrid::round_down(rn * rn * (1.0 - 1e-6));
+        const double widen = 1e-6 * (double)g.d_near + 1e-30;
+        for (int k = 0; k < 3; k++) {
+          A.grid_lo_n[k] = ptgrid::round_down((double)g.lo[k] - widen);
+          A.grid_hi_n[k] = ptgrid::round_up((double)g.hi[k] + widen);
+        }
+      }
       const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
       const size_t need_all = need_cells + (size_t)g.n_entries * 16;
       if (need_all + park1024 <= lds_max) {

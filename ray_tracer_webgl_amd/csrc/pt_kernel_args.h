@@ -67,7 +67,8 @@ struct PtKernelArgs {
   uint32_t n_cells;
   uint32_t grid_n[3];
   float grid_lo[3], grid_hi[3], grid_h[3], grid_inv_h[3];
-  float grid_d_near;               // rays with |o - c0| + s0 <= d_near walk the cells
+  float grid_r2_near;              // rays with |o - c0|^2 <= this ((0.9999 d_near - s0)^2) walk the cells
+  float grid_lo_n[3], grid_hi_n[3];  // [lo, hi] widened by 1e-6 d_near: the entry slab test of those rays
   uint32_t lds_scene_bytes;        // dynamic LDS taken by the staged scene; the parked path state follows
   uint32_t carry_lanes;            // the walk moves on when fewer lanes than this (and less than half) still walk
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv

@@ -33,6 +33,9 @@
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
 #define PT_LONG_ITEM_SEGMENTS 384u // ~2x the mean item of config 2; see the priority note below
+#ifndef PT_PARKING
+#define PT_PARKING 1 // walk kernels: park the path state in LDS during the walk (fewer VGPRs -> more waves)
+#endif
 #define PT_COOP_MAX_LIVE 16 // tail mode when at most this many lanes of a wave hold a ray
 
 // hip's __ballot takes an int: the bool -> int -> "!= 0" round trip costs two VALU ops per use
@@ -271,13 +274,17 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
   // (recomputed where needed rather than kept in a VGPR for the kernel's lifetime)
 #define lane (threadIdx.x & 63u)
-  auto div_ = [](uint32_t n, const PtDiv& dv) -> uint32_t {
-    const uint32_t t = __umulhi(dv.m, n);
-    return (t + ((n - t) >> dv.s1)) >> dv.s2;
+  auto div_ = [](uint32_t n, uint32_t m, uint32_t s1, uint32_t s2) -> uint32_t {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> s1)) >> s2;
   };
   const uint32_t n_spheres = A.n_spheres;
-  const float fw = A.fw, fh = A.fh;
-  const V3 cam_o = mk(A.origin[0], A.origin[1], A.origin[2]);
+  // K: the same argument block, read from the kernarg segment AT THE POINT OF USE (scalar loads
+  // through the scalar cache).  The once-per-wave-step sections (item decode, camera ray, walk
+  // set-up) use it so that their ~70 uniforms do not sit in SGPRs (or spill to VGPR lanes)
+  // across the walk and the shading code.
+  typedef const PtKernelArgs __attribute__((address_space(4))) karg_t;
+  karg_t& K = *(karg_t*)__builtin_amdgcn_kernarg_segment_ptr();
 
   // ---- per-lane path state ---------------------------------------------------------------------
   bool alive = false;     // lane holds a live ray
@@ -324,19 +331,20 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   auto start_sample = [&]() {
     float r0, r1;
     hash2(seed, r0, r1);
-    float s = st_s + r0 / fw;
-    float t = st_t + r1 / fh;
+    float s = st_s + r0 / K.fw;
+    float t = st_t + r1 / K.fh;
     float ua = hash1(seed); // random_in_unit_circle :123-129, consumed even if lens_radius == 0
     float sa, ca;
     sincos2pi(ua, sa, ca);
     float rr = __builtin_sqrtf(hash1(seed));
-    float rdx = A.lens_radius * (rr * ca);
-    float rdy = A.lens_radius * (rr * sa);
-    V3 off = mk(fma_(A.cam_v[0], rdy, A.cam_u[0] * rdx), fma_(A.cam_v[1], rdy, A.cam_u[1] * rdx),
-                fma_(A.cam_v[2], rdy, A.cam_u[2] * rdx));
-    V3 dd = mk(fma_(t, A.vertical[0], fma_(s, A.horizontal[0], A.llc[0])),
-               fma_(t, A.vertical[1], fma_(s, A.horizontal[1], A.llc[1])),
-               fma_(t, A.vertical[2], fma_(s, A.horizontal[2], A.llc[2])));
+    float rdx = K.lens_radius * (rr * ca);
+    float rdy = K.lens_radius * (rr * sa);
+    V3 off = mk(fma_(K.cam_v[0], rdy, K.cam_u[0] * rdx), fma_(K.cam_v[1], rdy, K.cam_u[1] * rdx),
+                fma_(K.cam_v[2], rdy, K.cam_u[2] * rdx));
+    V3 dd = mk(fma_(t, K.vertical[0], fma_(s, K.horizontal[0], K.llc[0])),
+               fma_(t, K.vertical[1], fma_(s, K.horizontal[1], K.llc[1])),
+               fma_(t, K.vertical[2], fma_(s, K.horizontal[2], K.llc[2])));
+    const V3 cam_o = mk(K.origin[0], K.origin[1], K.origin[2]);
     d = mk((dd.x - cam_o.x) - off.x, (dd.y - cam_o.y) - off.y, (dd.z - cam_o.z) - off.z);
     o = mk(cam_o.x + off.x, cam_o.y + off.y, cam_o.z + off.z);
     a = dot3(d, d);
@@ -372,28 +380,28 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       pool_next += cnt < avail ? cnt : avail;
       if (need && rank < avail) {
         uint32_t item = pool_base + rank;
-        uint32_t per_tile = 64u * A.n_passes;
-        uint32_t tile_pos = div_(item, A.div_per_tile);
+        uint32_t per_tile = 64u * K.n_passes;
+        uint32_t tile_pos = div_(item, K.div_per_tile.m, K.div_per_tile.s1, K.div_per_tile.s2);
         uint32_t rem_i = item - tile_pos * per_tile;
-        uint32_t tile = A.tile_order[tile_pos]; // heaviest tiles are dealt first
+        uint32_t tile = K.tile_order[tile_pos]; // heaviest tiles are dealt first
         uint32_t pass = rem_i >> 6, l = rem_i & 63u;
-        uint32_t ty = div_(tile, A.div_tiles_x), tx = tile - ty * A.tiles_x;
+        uint32_t ty = div_(tile, K.div_tiles_x.m, K.div_tiles_x.s1, K.div_tiles_x.s2), tx = tile - ty * K.tiles_x;
         uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
-        if (px < A.width && ly < A.local_rows) {
+        if (px < K.width && ly < K.local_rows) {
           uint32_t y = ly;
-          if (A.band_count > 1u) {
-            uint32_t b = div_(ly, A.div_band_rows), r = ly - b * A.band_rows;
-            y = (b * A.band_count + A.band_index) * A.band_rows + r;
+          if (K.band_count > 1u) {
+            uint32_t b = div_(ly, K.div_band_rows.m, K.div_band_rows.s1, K.div_band_rows.s2), r = ly - b * K.band_rows;
+            y = (b * K.band_count + K.band_index) * K.band_rows + r;
           }
           // static/shader.vert:8 + rasteriser: v_position at the pixel centre
-          float vx = (float)(2u * px + 1u) / fw - 1.0f;
-          float vy = (float)(2u * y + 1u) / fh - 1.0f;
-          float u_time = A.time0 + (float)pass;
+          float vx = (float)(2u * px + 1u) / K.fw - 1.0f;
+          float vy = (float)(2u * y + 1u) / K.fh - 1.0f;
+          float u_time = K.time0 + (float)pass;
           // init_global_seed, static/shader.frag:354-357
           seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
           st_s = (vx + 1.0f) * 0.5f; // :410
           st_t = (vy + 1.0f) * 0.5f;
-          slab_index = (pass * A.local_rows + ly) * A.width + px;
+          slab_index = (pass * K.local_rows + ly) * K.width + px;
           // only the launch's first pass reports its cost (atomicMax per pixel: the tile's
           // heaviest item): plenty for ordering tiles, and a memory-side atomic moves 64 B
           item_tile = pass == 0u ? tile : 0xffffffffu;
@@ -471,7 +479,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // want waves, i.e. few VGPRs: the part of the path state that the walk does not touch is
     // parked in LDS while it runs (14 dwords per lane, conflict-free, see `park`) and
     // fetched back for shading.  volatile: the values must not be forwarded in registers.
-    if constexpr (TREE) {
+    if constexpr (TREE && PT_PARKING) {
       lds_u32* ps = park;
       ps[0] = f2u(sum.x); ps[1] = f2u(sum.y); ps[2] = f2u(sum.z);
       ps[3] = f2u(col.x); ps[4] = f2u(col.y); ps[5] = f2u(col.z);
@@ -821,28 +829,31 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f);
       const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f);
       const bool posx = ix > 0.0f, posy = iy > 0.0f, posz = iz > 0.0f;
-      const float tdx = A.grid_h[0] * __builtin_fabsf(ix), tdy = A.grid_h[1] * __builtin_fabsf(iy),
-                  tdz = A.grid_h[2] * __builtin_fabsf(iz);
+      const float tdx = K.grid_h[0] * __builtin_fabsf(ix), tdy = K.grid_h[1] * __builtin_fabsf(iy),
+                  tdz = K.grid_h[2] * __builtin_fabsf(iz);
+      const int gnx = (int)K.grid_n[0], gny = (int)K.grid_n[1], gnz = (int)K.grid_n[2];
       const int sdx = posx ? 1 : -1;
-      const int sdy = posy ? (int)A.grid_n[0] : -(int)A.grid_n[0];
-      const int sdz = posz ? (int)(A.grid_n[0] * A.grid_n[1]) : -(int)(A.grid_n[0] * A.grid_n[1]);
+      const int sdy = posy ? gnx : -gnx;
+      const int sdz = posz ? gnx * gny : -(gnx * gny);
 
       // entry: where does the half-line meet the grid's box?
       if (!carried) { gactive = false; pend = 0u; }
       if (pt_ballot(fresh) != 0ull) {
-        const float px = o.x - A.bvh_c0[0], py = o.y - A.bvh_c0[1], pz = o.z - A.bvh_c0[2];
-        // D >= |o - C| for every gridded sphere; v_sqrt_f32 is good to 1 ulp, the comparison
-        // below and the far margin carry far more slack than that
-        const float D = __builtin_amdgcn_sqrtf(fma_(pz, pz, fma_(py, py, px * px))) + A.bvh_s0;
-        const bool near = D <= A.grid_d_near * 0.9999f;
-        // near rays: every registered box lies inside [lo, hi] (delta_g is part of it).  Far rays
-        // test the box inflated by their own delta(D) <= sqrt(40 u) D + 16 u rmax < 1.7e-3 D; if
-        // they enter they take the literal loop (PHASE 3) over the whole list.  1e-6 D (plus an
-        // absolute crumb for degenerate scenes) covers the rounding of the slab arithmetic.
-        const float mm = fma_(near ? 1e-6f : 1.7e-3f, D, 1e-30f);
-        const float t1x = ((A.grid_lo[0] - mm) - o.x) * ix, t2x = ((A.grid_hi[0] + mm) - o.x) * ix;
-        const float t1y = ((A.grid_lo[1] - mm) - o.y) * iy, t2y = ((A.grid_hi[1] + mm) - o.y) * iy;
-        const float t1z = ((A.grid_lo[2] - mm) - o.z) * iz, t2z = ((A.grid_hi[2] + mm) - o.z) * iz;
+        // near rays (|o - c0| + s0 <= d_near, tested on squares: grid_r2_near = (0.9999 d_near - s0)^2):
+        // every registered box lies inside [lo, hi] (delta_g is part of it); the host has widened
+        // grid_lo_n / grid_hi_n by 1e-6 d_near for the rounding of this slab arithmetic.  Far
+        // rays test the box inflated by their own delta(D) <= sqrt(40 u) D + 16 u rmax < 1.7e-3 D;
+        // if they enter they take the literal loop (PHASE 3) over the whole list.
+        const float px = o.x - K.bvh_c0[0], py = o.y - K.bvh_c0[1], pz = o.z - K.bvh_c0[2];
+        const float r2 = fma_(pz, pz, fma_(py, py, px * px));
+        const bool near = r2 <= K.grid_r2_near;
+        float mm = 0.0f;
+        if (pt_ballot(fresh && !near) != 0ull) // (rare) v_sqrt_f32 is good to 1 ulp, the factor carries 10 % slack
+          mm = near ? 0.0f : 1.7e-3f * (__builtin_amdgcn_sqrtf(r2) + K.bvh_s0);
+        const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+        const float t1x = fma_(K.grid_lo_n[0] - mm, ix, -oix), t2x = fma_(K.grid_hi_n[0] + mm, ix, -oix);
+        const float t1y = fma_(K.grid_lo_n[1] - mm, iy, -oiy), t2y = fma_(K.grid_hi_n[1] + mm, iy, -oiy);
+        const float t1z = fma_(K.grid_lo_n[2] - mm, iz, -oiz), t2z = fma_(K.grid_hi_n[2] + mm, iz, -oiz);
         const float tn = __builtin_fmaxf(
             __builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
             __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
@@ -859,10 +870,12 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         if (enter) {
           gactive = true;
           // the cell that holds the entry point (clamped: rounding may put it a hair outside)
-          const float fx = (fma_(d.x, tn, o.x) - A.grid_lo[0]) * A.grid_inv_h[0];
-          const float fy = (fma_(d.y, tn, o.y) - A.grid_lo[1]) * A.grid_inv_h[1];
-          const float fz = (fma_(d.z, tn, o.z) - A.grid_lo[2]) * A.grid_inv_h[2];
-          const int nx1 = (int)A.grid_n[0] - 1, ny1 = (int)A.grid_n[1] - 1, nz1 = (int)A.grid_n[2] - 1;
+          const float glx = K.grid_lo[0], gly = K.grid_lo[1], glz = K.grid_lo[2];
+          const float ghx = K.grid_h[0], ghy = K.grid_h[1], ghz = K.grid_h[2];
+          const float fx = (fma_(d.x, tn, o.x) - glx) * K.grid_inv_h[0];
+          const float fy = (fma_(d.y, tn, o.y) - gly) * K.grid_inv_h[1];
+          const float fz = (fma_(d.z, tn, o.z) - glz) * K.grid_inv_h[2];
+          const int nx1 = gnx - 1, ny1 = gny - 1, nz1 = gnz - 1;
           int cx = (int)__builtin_floorf(fx), cy = (int)__builtin_floorf(fy), cz = (int)__builtin_floorf(fz);
           cx = cx < 0 ? 0 : (cx > nx1 ? nx1 : cx);
           cy = cy < 0 ? 0 : (cy > ny1 ? ny1 : cy);
@@ -870,16 +883,16 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           // times at which the ray crosses the cell's far planes (the side follows the sign of
           // the CLAMPED reciprocal, so a zero component gets a plane it never reaches: +-1e18 times
           // a non-negative distance) — never before the entry time
-          const float bx = fma_((float)(cx + (posx ? 1 : 0)), A.grid_h[0], A.grid_lo[0]);
-          const float by = fma_((float)(cy + (posy ? 1 : 0)), A.grid_h[1], A.grid_lo[1]);
-          const float bz = fma_((float)(cz + (posz ? 1 : 0)), A.grid_h[2], A.grid_lo[2]);
-          tmx = __builtin_fmaxf((bx - o.x) * ix, tn);
-          tmy = __builtin_fmaxf((by - o.y) * iy, tn);
-          tmz = __builtin_fmaxf((bz - o.z) * iz, tn);
+          const float bx = fma_((float)(cx + (posx ? 1 : 0)), ghx, glx);
+          const float by = fma_((float)(cy + (posy ? 1 : 0)), ghy, gly);
+          const float bz = fma_((float)(cz + (posz ? 1 : 0)), ghz, glz);
+          tmx = __builtin_fmaxf(fma_(bx, ix, -oix), tn);
+          tmy = __builtin_fmaxf(fma_(by, iy, -oiy), tn);
+          tmz = __builtin_fmaxf(fma_(bz, iz, -oiz), tn);
           // steps left before the walk leaves the grid, + 1, three 10-bit fields
           rem = (uint32_t)((posx ? nx1 - cx : cx) + 1) | ((uint32_t)((posy ? ny1 - cy : cy) + 1) << 10) |
                 ((uint32_t)((posz ? nz1 - cz : cz) + 1) << 20);
-          cell = ((uint32_t)cz * A.grid_n[1] + (uint32_t)cy) * A.grid_n[0] + (uint32_t)cx;
+          cell = ((uint32_t)cz * (uint32_t)gny + (uint32_t)cy) * (uint32_t)gnx + (uint32_t)cx;
         }
       }
 
@@ -1063,7 +1076,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       closest_w = closest;
     }
 
-    if constexpr (TREE) {
+    if constexpr (TREE && PT_PARKING) {
       lds_u32* ps = park;
       sum = mk(u2f(ps[0]), u2f(ps[1]), u2f(ps[2]));
       col = mk(u2f(ps[3]), u2f(ps[4]), u2f(ps[5]));

@@ -744,7 +744,8 @@ def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):
     t.render_passes(2)
     ref, seg = ora.render(sc.spheres, sc.params, 2)
     assert_bit_equal(t.accum(), ref, "after pt_tune")
-    assert t.stats().segments == seg and t.stats().geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH)
+    assert t.stats().segments == seg and t.stats().geometry_path in (abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH,
+                                                                           abi.PT_GEOM_GRID)
     t.close()
 
 
