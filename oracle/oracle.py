@@ -32,9 +32,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PT_ORACLE_LIB", LIB_PATH)  # bench.py's cpu_baseline leg: the -march=native rebuild
+    if not os.path.exists(path):
         build()
-    L = C.CDLL(LIB_PATH)
+        path = LIB_PATH
+    L = C.CDLL(path)
     fp = C.POINTER(C.c_float)
     sp = C.POINTER(abi.PtSphere)
     pp = C.POINTER(abi.PtParams)

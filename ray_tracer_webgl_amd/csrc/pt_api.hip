@@ -656,6 +656,10 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   uint32_t bvh_block = 0;
   A.coop_max_live = 16;
   A.carry_lanes = c->carry_lanes;
+  A.long_item_segments = 6u * (uint32_t)p.samples_per_pixel;
+#ifdef PT_DEV_KNOBS
+  if (const char* e = getenv("PT_LONG_ITEM")) A.long_item_segments = (uint32_t)atoi(e);
+#endif
   if (path == PT_GEOM_BVH || path == PT_GEOM_GRID) {
     const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
     const size_t park1024 = (size_t)PT_PARK_STRIDE * 4 * 1024;

@@ -32,7 +32,6 @@
 #define PT_MAX_T 1e5f   // static/shader.frag:5
 #define PT_MIN_T 0.001f // static/shader.frag:6
 #define PT_TWO_PI 6.2831855f
-#define PT_LONG_ITEM_SEGMENTS 384u // ~2x the mean item of config 2; see the priority note below
 #ifndef PT_PARKING
 #define PT_PARKING 1 // walk kernels: park the path state in LDS during the walk (fewer VGPRs -> more waves)
 #endif
@@ -473,7 +472,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // A launch cannot end before its longest (pixel, pass) stream has run its serial course,
     // so waves carrying a long-running item get issue priority: their iterations complete
     // sooner at no cost in total throughput (the SIMD arbitrates by priority, then age).
-    if (pt_ballot(alive && item_segs > PT_LONG_ITEM_SEGMENTS) != 0ull) __builtin_amdgcn_s_setprio(3);
+    if (pt_ballot(alive && item_segs > A.long_item_segments) != 0ull) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
     // The walks are latency-bound (per-lane LDS gathers, short dependent loops), so they
     // want waves, i.e. few VGPRs: the part of the path state that the walk does not touch is

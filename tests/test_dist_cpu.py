@@ -81,3 +81,28 @@ def test_band_helpers():
     assert ptdist.max_local_rows(1080, 8, 8) == 136  # 135 bands of 8 rows: ranks 0..6 get 17
     assert sum(abi.local_rows(1080, 8, r, 8) for r in range(8)) == 1080
     assert ptdist.max_local_rows(5, 8, 2) == 5
+
+
+def _run_bench(*extra):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo"] + list(extra),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` from a bare shell (no torchrun, WORLD_SIZE unset): the parent
+    starts N ranks, they rendezvous on 127.0.0.1, rank 0's JSON line comes back through the
+    parent.  --spawn-selftest keeps the ranks off the GPU, so this runs on CPU."""
+    rc, lines, err = _run_bench("--gpus", "3", "--spawn-selftest", "ok")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]["ranks"] == 3 and lines[0]["rank_sum"] == 6.0 and lines[0]["local_rank"] == 0
+
+
+def test_bench_reports_a_failed_rank():
+    rc, lines, err = _run_bench("--gpus", "2", "--spawn-selftest", "fail")
+    assert rc != 0
