@@ -4,7 +4,7 @@
   metric   Mray/s (ray segments = hit_world invocations per second) at 1920x1080
   workload config 2: Shirley cover scene (484 spheres), 1920x1080, 50 bounces, 1024 spp
   step     one pass of the hot path over one batch = 64 samples for every pixel, rendered as
-           `--passes-per-step` (4) seeds of `--spp-per-pass` (16) samples each (u_time = 4 * step + j:
+           `--passes-per-step` (4) seeds of `--spp-per-pass` (16) samples each (u_time = (4 * step + j) x 0.3618:
            the reference also accumulates many low-spp frames with distinct u_time, README.md:6);
            the default 16 steps are exactly the config's 1024 spp "converged frame".  Steps are
            enqueued `--steps-per-launch` at a time through pt_render_passes (one persistent kernel
@@ -183,6 +183,7 @@ def main():
     p = sc.params.copy()
     band_rows = args.band_rows
     p.band_rows, p.band_index, p.band_count = ptdist.band_of(rank, world, band_rows)
+    p.time_step = abi.PT_TIME_STEP_DECORRELATED  # independent passes (include/ptrace.h)
 
     pt = PathTracer(p.width, p.height, device=local_rank, use_torch=True)
     pt.set_spheres(sc.spheres)
@@ -205,7 +206,8 @@ def main():
         while done < k:
             n = min(spl, k - done)
             q = p.copy()
-            q.time = float(first_time + done * pps)  # pass j of this launch uses u_time = time + j
+            q.time = float(first_time)
+            q.first_pass = done * pps  # pass j of this launch uses u_time = time + (first_pass + j) * time_step
             pt.set_params(q)
             pt.render_passes(n * pps)  # asynchronous on torch's current stream
             done += n

@@ -26,6 +26,7 @@ pub struct PtParams {            // == uniform block, static/shader.frag:79-99
     pub render_count: i32, pub should_average: i32, pub last_frame_weight: f32,
     pub background_mode: i32,
     pub band_rows: u32, pub band_index: u32, pub band_count: u32,
+    pub time_step: f32, pub first_pass: u32,
 }
 
 #[repr(C)] pub struct PtCtx { _private: [u8; 0] }

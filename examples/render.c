@@ -10,6 +10,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "ptrace.h"
 
@@ -38,6 +39,7 @@ int main(int argc, char** argv) {
   CHECK(pt_reserve_passes(ctx, frames));
 
   PtParams p;
+  memset(&p, 0, sizeof p);
   CHECK(pt_state_to_params(st, 0.0, &p));             /* Uniforms::run_setters: paused -> 25 spp */
   p.background_mode = PT_BG_SKY;
   p.band_rows = 8; p.band_index = 0; p.band_count = 1;

@@ -134,7 +134,20 @@ typedef struct PtParams {
   uint32_t band_rows;
   uint32_t band_index;
   uint32_t band_count;
+  /*
+   * pt_render_passes: pass p of the call renders with
+   *     u_time = time + float(first_pass + p) * time_step      (fp32 multiply, then add; step 0 means 1)
+   * so a frame rendered as several calls (first_pass = passes done so far) has the bits of one
+   * call, whatever the step.  Whole-number steps make consecutive passes REUSE each other's random
+   * numbers (the seed advances by .1 per draw, static/shader.frag:22, so pass p + 1 walks the
+   * seeds pass p reaches ten draws later): measured +27 % variance of the accumulated frame.
+   * The reference's own u_time is performance.now(), which never lines up like that; a step such
+   * as PT_TIME_STEP_DECORRELATED keeps the passes independent (tests/test_reference_pins.py).
+   */
+  float time_step;
+  uint32_t first_pass;
 } PtParams;
+#define PT_TIME_STEP_DECORRELATED 0.3618034f /* 0.1 x (3 + 1/golden ratio): multiples never near a multiple of .1 */
 
 /*
  * Inputs of State::update_pipeline (src/state.rs:319-347) / State::default (:98-125): the

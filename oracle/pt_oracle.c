@@ -623,13 +623,15 @@ ORA_API uint64_t ora_render_pass(const PtSphere* spheres, uint32_t n, const PtPa
   return seg;
 }
 
-/* n_passes passes with u_time = p->time + pass (fp32 add), accumulated in pass order. */
+/* n_passes passes with u_time = p->time + float(first_pass + pass) * time_step (fp32 multiply, then add; a
+ * step of 0 means 1), accumulated in pass order. */
 ORA_API uint64_t ora_render_passes(const PtSphere* spheres, uint32_t n, const PtParams* p,
                                    uint32_t n_passes, float* accum, uint32_t x0, uint32_t x1,
                                    uint32_t y0, uint32_t y1, uint32_t nthreads) {
   uint64_t seg = 0;
   for (uint32_t k = 0; k < n_passes; k++)
-    seg += ora_render_pass(spheres, n, p, p->time + (float)k, accum, x0, x1, y0, y1, nthreads);
+    seg += ora_render_pass(spheres, n, p, p->time + (float)(p->first_pass + k) * (p->time_step != 0.0f ? p->time_step : 1.0f), accum, x0,
+                           x1, y0, y1, nthreads);
   return seg;
 }
 

@@ -604,6 +604,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   }
   A.lens_radius = p.lens_radius;
   A.time0 = p.time;
+  A.time_step = p.time_step != 0.0f ? p.time_step : 1.0f;
+  A.first_pass = p.first_pass;
   A.spp = p.samples_per_pixel;
   A.max_depth = p.max_depth;
   A.background_mode = p.background_mode;

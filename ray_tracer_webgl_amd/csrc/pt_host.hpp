@@ -351,6 +351,10 @@ inline void to_params(const State& s, double now_ms, PtParams& p) {
   p.render_count = (int32_t)s.render_count;
   p.should_average = s.should_average ? 1 : 0;
   p.last_frame_weight = s.last_frame_weight;
+  // build extensions the reference has no counterpart for: sky background, all rows, whole-number pass times
+  p.background_mode = PT_BG_SKY;
+  p.band_rows = 0; p.band_index = 0; p.band_count = 1;
+  p.time_step = 0.0f; p.first_pass = 0;
 }
 
 // webgl::set_geometry narrowing (webgl.rs:232-272)

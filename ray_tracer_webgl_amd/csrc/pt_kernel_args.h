@@ -36,7 +36,8 @@ struct PtKernelArgs {
   // uniform block, static/shader.frag:79-99 (see include/ptrace.h PtParams)
   float origin[3], horizontal[3], vertical[3], llc[3], cam_u[3], cam_v[3];
   float lens_radius;
-  float time0;  // pass p renders with u_time = time0 + float(p)
+  float time0, time_step;  // pass p renders with u_time = time0 + float(first_pass + p) * time_step
+  uint32_t first_pass;
   int32_t spp;
   int32_t max_depth;
   int32_t background_mode;

@@ -395,7 +395,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           // static/shader.vert:8 + rasteriser: v_position at the pixel centre
           float vx = (float)(2u * px + 1u) / K.fw - 1.0f;
           float vy = (float)(2u * y + 1u) / K.fh - 1.0f;
-          float u_time = K.time0 + (float)pass;
+          float u_time = K.time0 + (float)(K.first_pass + pass) * K.time_step;
           // init_global_seed, static/shader.frag:354-357
           seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
           st_s = (vx + 1.0f) * 0.5f; // :410

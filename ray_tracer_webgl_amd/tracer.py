@@ -203,7 +203,7 @@ def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=
     while done < scene.n_passes:
         k = min(per, scene.n_passes - done)
         q = p.copy()
-        q.time = float(np.float32(scene.params.time) + np.float32(done))
+        q.first_pass = scene.params.first_pass + done  # u_time = time + float(first_pass + p) * time_step
         pt.set_params(q)
         pt.render_passes(k)
         done += k
