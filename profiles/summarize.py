@@ -21,6 +21,21 @@ for f in glob.glob(os.path.join(d, "kt", "**", "*_kernel_stats.csv"), recursive=
                 float(row["MaxNs"]) / 1e6, row["Percentage"]))
             out.setdefault("kernel_stats", {})[row["Name"]] = {
                 "calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6}
+# the other configs: every trace-kernel dispatch in order (pt_tune's trials of each usable path, then
+# the measured launch = the last dispatch before the next config's first)
+for f in glob.glob(os.path.join(d, "kt_configs", "**", "*_kernel_trace.csv"), recursive=True):
+    print("== trace-kernel dispatches of tools/config_sweep.py config3 config4 config5 default (%s)" % os.path.relpath(f, d))
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("pt_trace")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
+        print("  %-32s %9.3f ms  grid %s x wg %s  lds %s B  vgpr %s" % (
+            r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size", "?"),
+            r.get("Workgroup_Size", "?"), r.get("LDS_Block_Size", "?"), r.get("VGPR_Count", "?")))
+for f in glob.glob(os.path.join(d, "kt_configs.log")):
+    print("== tools/config_sweep.py output under the profiler")
+    for line in open(f):
+        if line.startswith(("config", "default")):
+            print("  " + line.rstrip())
 ctr = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
@@ -62,7 +77,9 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
     out["pt_trace_kernel_hbm_bytes_per_launch"] = int(traffic)
     print("  HBM traffic per launch (WRITE_SIZE + 2*FETCH_SIZE): %.4g bytes" % traffic)
     rec = {"pt_trace_kernel_hbm_bytes_per_launch": int(traffic), "kernel": out.get("pmc_kernel"),
-           "workload": "bench.py --steps 16 --warmup 16 (config 2, 16 passes per launch; pt_tune runs each usable path, then the timed launches use the fastest)",
+           "workload": "bench.py --steps 16 --warmup 16 (config 2, 64 passes of 16 spp per launch; pt_tune runs each usable path, then the timed launches use the fastest)",
+           "spp_per_pass": 16, "passes_per_launch": 64, "hbm_bytes_per_pass": int(traffic / 64),
+           "profile": "profiles/" + os.path.basename(os.path.normpath(d)).replace("prof_", "") + "_summary.txt",
            "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]}
     # what the kernel actually issued (the hierarchy walk skips most of the algorithmic tests):
     # wave-level VALU instructions per launch and the share of the chip's VALU issue slots they

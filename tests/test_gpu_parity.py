@@ -300,6 +300,44 @@ def test_passes_batched_equals_separate_launches(ora):
     assert_bit_equal(a1, ref, "6 passes vs oracle")
     for t in (t1, t2, t3):
         t.close()
+    # the same with pass times that are not whole numbers (PtParams.time_step / first_pass): u_time is
+    # time + float(first_pass + p) * step whichever launch renders pass p
+    sc = scenes.config2(96, 54, 3, 7, 12)
+    sc.params.time, sc.params.time_step = 2.5, abi.PT_TIME_STEP_DECORRELATED
+    ref, seg = ora.render(sc.spheres, sc.params, 7)
+    for ppl in (7, 1, 3):
+        t, a = render_scene(sc, passes_per_launch=ppl)
+        assert_bit_equal(a, ref, "time_step, %d passes per launch" % ppl)
+        assert t.stats().segments == seg
+        t.close()
+    one = sc.params.copy()
+    one.time_step = 1.0
+    other, _ = ora.render(sc.spheres, one, 7)
+    assert not np.array_equal(other, ref)
+
+
+def test_frame_loop_reproduces_the_shaded_windows_of_the_reference_screenshot():
+    """The product, driven the way the reference drives WebGL (app.FrameLoop in reference mode:
+    one 1-spp frame per tick, blended into RGBA8 ping-pong textures by pt_blend_rgba8), lands on
+    the reference's own screenshot of State::default: the window means of
+    tests/golden/reference_shaded_windows.npz within 1.5/255 (tests/test_reference_pins.py does
+    the same with the oracle and explains why a converged linear render is 5-16/255 brighter)."""
+    from ray_tracer_webgl_amd.app import FrameLoop
+
+    z = np.load(os.path.join(GOLDEN, "reference_shaded_windows.npz"))
+    w, h = (int(v) for v in z["size"])
+    loop = FrameLoop(w, h, mode="reference")
+    loop.state.set_flags(is_paused=False)  # 1 spp per frame (src/state.rs:127)
+    for k in range(320):
+        assert loop.frame(3000.0 + 16.7 * k) is True
+    canvas = loop.canvas[..., :3].astype(np.float64)
+    worst = 0.0
+    for name, box, shot in zip(z["names"], z["boxes"], z["pixels"]):
+        x0, x1, y0, y1 = (int(v) for v in box)
+        d = np.abs(canvas[y0:y1, x0:x1].mean((0, 1)) - shot.astype(np.float64).mean((0, 1))).max()
+        worst = max(worst, float(d))
+        assert d <= 1.5, (str(name), d)
+    loop.close()
 
 
 def test_row_band_partition_bit_exact(ora):

@@ -74,20 +74,53 @@ def test_config2_full(ora):
     t.close()
 
 
-def test_config3_4k(ora):
-    """Cover scene at 3840x2160; 4096 spp is 64 passes — here 8 passes (512 spp) on one GPU plus
-    the full 64-pass spot check of a window through pass batching."""
-    sc = scenes.config3(n_passes=8)
+def test_config2_as_the_bench_renders_it(ora):
+    """The same frame in the pass shape bench.py uses: 64 passes of 16 spp with pass times that do
+    not line up with the seed step (PtParams.time_step).  Oracle windows at the full 1024 spp,
+    batching invariance (16 + 48 passes through first_pass), the committed checksum."""
+    sc = scenes.config2(1920, 1080, 16, 64, 50)
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
     t, a = render_scene(sc)
-    assert np.all(a[..., 3] == 512.0) and np.isfinite(a).all()
+    st = t.stats()
+    assert st.total_spp == 1024 and np.all(a[..., 3] == 1024.0) and np.isfinite(a).all()
+    spot_check(ora, sc, a, (1000, 1012, 400, 408))
+    spot_check(ora, sc, a, (700, 708, 200, 206))
+    t2, b = render_scene(sc, passes_per_launch=48)  # 48 + 16
+    assert np.array_equal(bits(a), bits(b)) and t2.stats().segments == st.segments
+    with open(os.path.join(GOLDEN, "full_frame_digests.json")) as f:
+        want = json.load(f).get("config2_1920x1080_64x16spp_decorrelated")
+    assert want is not None and digest(a) == want["sha256"] and st.segments == want["segments"]
+    t.close()
+    t2.close()
+
+
+def test_config3_4k(ora):
+    """BASELINE config 3 as stated: the cover scene at 3840x2160, 4096 spp (64 passes of 64),
+    50 bounces — the whole frame on one GPU, an oracle window at the full 4096 spp, and the row
+    partition of the 8-GPU run: all eight ranks' interleaved bands, rendered one after the other
+    on this GPU, reassemble the full frame bit for bit (each rank's share is the dist.py layout
+    the RCCL all_gather moves)."""
+    sc = scenes.config3()
+    assert sc.n_passes == 64 and sc.params.samples_per_pixel == 64
+    t, a = render_scene(sc)
+    st = t.stats()
+    assert st.total_spp == 4096 and np.all(a[..., 3] == 4096.0) and np.isfinite(a).all()
     spot_check(ora, sc, a, (2000, 2008, 800, 806))
+    spot_check(ora, sc, a, (3836, 3840, 2154, 2160))  # sky corner, last tile column / row
+    t.close()
     out = np.zeros_like(a)
-    for r in (0, 5):  # two of the eight ranks' bands
+    seg = 0
+    shares = []
+    for r in range(8):
         tb, part = render_scene(sc, band=(8, r, 8))
         ys = abi.owned_rows(2160, 8, r, 8)
-        assert np.array_equal(bits(part), bits(a[ys]))
+        assert part.shape[0] == len(ys)
+        out[ys] = part
+        shares.append(tb.stats().segments)
+        seg += shares[-1]
         tb.close()
-    t.close()
+    assert np.array_equal(bits(out), bits(a)) and seg == st.segments
+    assert max(shares) < 1.04 * seg / 8  # interleaved bands: no rank carries more than 4 % extra
 
 
 def test_config4_room_8192spp(ora):

@@ -9,6 +9,8 @@ cases = [("config2", scenes.config2(1920, 1080, 64, 16, 50), 16),
          ("config5", scenes.config5(1920, 1080, 64, 4, 50), 4),
          ("config3", scenes.config3(3840, 2160, 64, 8, 50), 8),
          ("default", scenes.default_scene(1280, 702, 25, 8, 16), 16)]
+# one launch per config after pt_tune (the timed launch is the LAST trace-kernel dispatch of each
+# config in a rocprofv3 kernel trace; the ones before it are pt_tune's trials of every usable path)
 for name, sc, n in cases:
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
