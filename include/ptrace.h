@@ -286,10 +286,10 @@ int pt_build_bvh(const PtSphere* spheres, uint32_t n, float* nodes, size_t node_
                  float* nodes32, size_t n_floats32);
 /* The grid pt_set_spheres builds for PT_GEOM_GRID, on the host (no device needed; tests check the
  * registration invariant): dims9 = {n[3] as floats' bit patterns are NOT used: see counts}, i.e.
- * counts8 = {n.x, n.y, n.z, n_cell_entries, n_always, n_entries, max groups per cell, non-empty
+ * counts8 = {n.x, n.y, n.z, n_cell_entries, n_always, n_entries, max entries per cell, non-empty
  * cells}; geom12 = {lo.xyz, h.xyz, hi.xyz, c0.xyz}; margin4 = {s0, rmin, rmax, d_near};
- * delta_g = registration inflation; cells = n.x*n.y*n.z records (first group | groups << 24, a
- * group = 4 entries), entries = 4 floats each {cx, cy, cz, r*r}, entry_index = original sphere
+ * delta_g = registration inflation; cells = n.x*n.y*n.z records (first entry | entries << 24),
+ * entries = 4 floats each {cx, cy, cz, r*r}, entry_index = original sphere
  * index per entry (0xffffffff = padding).  Array pointers may be NULL (sizes only); capacities in
  * elements.  PT_ERR_NOT_READY when the scene gets no grid, PT_ERR_CAPACITY when an array is too small. */
 int pt_build_grid(const PtSphere* spheres, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,

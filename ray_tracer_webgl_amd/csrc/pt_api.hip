@@ -411,8 +411,8 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
       PT_HIP(c, hipMalloc(&c->d_grid_cells, n_cells_pad * sizeof(uint32_t)));
       c->grid_cell_cap = n_cells_pad;
     }
-    // + one group of slack: lanes without a cell under test read (and discard) the group their
-    // stale record points at, which may be the one behind the last
+    // + four entries of slack: a leaf round reads four consecutive entries whatever the cell's
+    // count (and lanes without a cell under test read, and discard, wherever their stale record points)
     const size_t n_ent_pad = (size_t)grid.n_entries + 4u;
     if (n_ent_pad > c->grid_entry_cap) {
       if (c->d_grid_entries) PT_HIP(c, hipFree(c->d_grid_entries));

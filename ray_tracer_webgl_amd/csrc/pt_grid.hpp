@@ -46,10 +46,12 @@
 // loads, as the list kernels test every sphere (at most kMaxAlways).
 //
 // Layout produced:
-//   cells   : n[0]*n[1]*n[2] records, x fastest: first group | n_groups << 24; a GROUP is four
-//             consecutive entries (the unit one leaf round of the kernel tests)
-//   entries : {cx, cy, cz, r*r} copies; the cells' groups first (padded with entries that can
-//             never pass: r*r = -inf), then the always-tested spheres (padded to four)
+//   cells   : n[0]*n[1]*n[2] records, x fastest: first entry | n_entries << 24 (a leaf round of the
+//             kernel tests four consecutive entries and masks those beyond the cell's count)
+//   entries : {cx, cy, cz, r*r} copies, cell after cell without padding (config 2: 1 081 entries
+//             for 480 gridded spheres — 17 KB of LDS, which is what lets six waves per SIMD
+//             fit), then the always-tested spheres, padded to four with entries that can never
+//             pass (r*r = -inf)
 //   entry_index : original sphere index per entry (0xffffffff = padding)
 #pragma once
 #include <algorithm>
@@ -62,7 +64,7 @@
 namespace ptgrid {
 
 constexpr uint32_t kMaxAlways = 32;   // spheres tested for every ray
-constexpr uint32_t kMaxGroups = 255;  // groups of four entries per cell (8-bit field)
+constexpr uint32_t kMaxCellEntries = 255;  // entries per cell (8-bit field)
 constexpr uint32_t kMaxAxis = 1023;   // cells per axis (10-bit fields in the walk's step counter)
 
 struct Grid {
@@ -77,7 +79,7 @@ struct Grid {
   float s0 = 0, rmin = 0, rmax = 0;
   float d_near = 0;   // rays with |o - c0|_2 + s0 <= d_near may walk the cells
   float delta_g = 0;  // registration inflation
-  uint32_t max_groups = 0, nonempty = 0;
+  uint32_t max_cell_entries = 0, nonempty = 0;
 };
 
 inline float round_up(double v) {
@@ -235,24 +237,21 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     for (int fill = 0; fill < 2; fill++) {
       std::vector<uint32_t> cursor;
       if (fill) {
-        // groups of four per cell
         g.cells.assign(n_cells, 0);
-        uint32_t group = 0;
-        g.max_groups = 0; g.nonempty = 0;
+        uint32_t first = 0;
+        g.max_cell_entries = 0; g.nonempty = 0;
         for (size_t c = 0; c < n_cells; c++) {
-          const uint32_t ng = (count[c] + 3u) / 4u;
-          if (ng > kMaxGroups) { ok = false; break; }
-          g.cells[c] = group | (ng << 24);
-          group += ng;
-          g.max_groups = std::max(g.max_groups, ng);
-          g.nonempty += ng ? 1u : 0u;
-          if (group >= (1u << 24)) { ok = false; break; }
+          if (count[c] > kMaxCellEntries) { ok = false; break; }
+          g.cells[c] = first | (count[c] << 24);
+          first += count[c];
+          g.max_cell_entries = std::max(g.max_cell_entries, count[c]);
+          g.nonempty += count[c] ? 1u : 0u;
+          if (first >= (1u << 24) - 8u) { ok = false; break; }
         }
         if (!ok) break;
-        g.n_cell_entries = group * 4u;
+        g.n_cell_entries = first;
         g.entries.assign((size_t)g.n_cell_entries * 4, 0.f);
         g.entry_index.assign(g.n_cell_entries, 0xffffffffu);
-        for (uint32_t e = 0; e < g.n_cell_entries; e++) g.entries[4 * (size_t)e + 3] = -std::numeric_limits<float>::infinity();
         cursor.assign(n_cells, 0);
       }
       for (uint32_t i = 0; i < n; i++) {  // ascending index: deterministic layout
@@ -264,7 +263,7 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
             for (uint32_t x = a[0]; x <= b[0]; x++) {
               const size_t c = ((size_t)z * g.n[1] + y) * g.n[0] + x;
               if (!fill) { count[c]++; continue; }
-              const uint32_t e = (g.cells[c] & 0xffffffu) * 4u + cursor[c]++;
+              const uint32_t e = (g.cells[c] & 0xffffffu) + cursor[c]++;
               std::memcpy(&g.entries[4 * (size_t)e], geom + 4 * (size_t)i, 16);
               g.entry_index[e] = i;
             }
@@ -278,7 +277,7 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
       g.entry_index.push_back(i);
     }
     g.n_always = n_alw;
-    while ((g.entry_index.size() & 3u) != 0) {
+    while (((g.entry_index.size() - g.n_cell_entries) & 3u) != 0) {
       const float pad[4] = {0.f, 0.f, 0.f, -std::numeric_limits<float>::infinity()};
       g.entries.insert(g.entries.end(), pad, pad + 4);
       g.entry_index.push_back(0xffffffffu);

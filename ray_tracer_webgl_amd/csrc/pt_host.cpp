@@ -146,7 +146,7 @@ PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float
   if (!regular || !ptgrid::build(geom.data(), radii.data(), n, &g)) return PT_ERR_NOT_READY;
   if (counts8) {
     counts8[0] = g.n[0]; counts8[1] = g.n[1]; counts8[2] = g.n[2]; counts8[3] = g.n_cell_entries;
-    counts8[4] = g.n_always; counts8[5] = g.n_entries; counts8[6] = g.max_groups; counts8[7] = g.nonempty;
+    counts8[4] = g.n_always; counts8[5] = g.n_entries; counts8[6] = g.max_cell_entries; counts8[7] = g.nonempty;
   }
   if (geom12)
     for (int k = 0; k < 3; k++) { geom12[k] = g.lo[k]; geom12[3 + k] = g.h[k]; geom12[6 + k] = g.hi[k]; geom12[9 + k] = g.c0[k]; }

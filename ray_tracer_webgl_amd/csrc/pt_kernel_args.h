@@ -64,7 +64,7 @@ struct PtKernelArgs {
   uint32_t n_nodes, n_tree_slots, n_slots, n_outliers;
   float bvh_c0[3], bvh_s0;         // hierarchy: per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6; grid: D = |o - c0| + s0
   // uniform grid (PT_GEOM_GRID)
-  const uint32_t* grid_cells;      // n_cells records (padded to 16 B): first group | groups << 24
+  const uint32_t* grid_cells;      // n_cells records (padded to 16 B): first entry | entries << 24
   uint32_t n_cells;
   uint32_t grid_n[3];
   float grid_lo[3], grid_hi[3], grid_h[3], grid_inv_h[3];

@@ -316,7 +316,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   uint32_t cur = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_cnt = 0;
   uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q_cnt = 0;
   // grid: boundary-crossing times, linear cell index, steps left per axis (3 x 10 bit, +1),
-  // the cell being tested (first group | groups << 24), its exit time
+  // the cell being tested (first untested entry | entries left << 24), its exit time
   float tmx = 0.f, tmy = 0.f, tmz = 0.f, t_exit = 0.f;
   uint32_t cell = 0, rem = 0, pend = 0;
   bool gactive = false;
@@ -930,8 +930,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         if (m_has == 0ull) break; // no cell under test and nobody can move: every walk is over
         PT_COUNT(n_leaf_it, n_leaf_ln, m_has);
         {
-          // one group of four entries of the cell under test
-          const uint32_t base = (pend & 0xffffffu) << 2;
+          // four consecutive entries of the cell under test (those beyond its count belong to the
+          // next cell or to the slack behind the array: tested, then masked)
+          const uint32_t base = pend & 0xffffffu;
+          const uint32_t left = pend >> 24;
           const float4 g0 = slot_at(base), g1 = slot_at(base + 1u), g2 = slot_at(base + 2u), g3 = slot_at(base + 3u);
           PT_TEST(g0, hb0, cc0, ds0)
           PT_TEST(g1, hb1, cc1, ds1)
@@ -941,7 +943,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           if (has) {
             mask = (PT_PASSES(hb0, cc0, ds0) ? 1u : 0u) | (PT_PASSES(hb1, cc1, ds1) ? 2u : 0u) |
                    (PT_PASSES(hb2, cc2, ds2) ? 4u : 0u) | (PT_PASSES(hb3, cc3, ds3) ? 8u : 0u);
-            pend = pend + 1u - (1u << 24); // next group, one fewer
+            mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
+            pend = left > 4u ? (base + 4u) | ((left - 4u) << 24) : 0u;
           }
           PT_EXACT_GROUP(base, mask)
           // the cell is done: can anything registered only in later cells still win?

@@ -42,7 +42,7 @@ def build(spheres):
     rc = lib.pt_build_grid(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), vp(cells), cells.size, vp(entries),
                            entries.size, vp(index), index.size)
     return rc, dict(n=counts[:3].astype(np.int64), n_cell_entries=int(counts[3]), n_always=int(counts[4]),
-                    n_entries=int(counts[5]), max_groups=int(counts[6]), nonempty=int(counts[7]), lo=geom[0:3], h=geom[3:6],
+                    n_entries=int(counts[5]), max_entries=int(counts[6]), nonempty=int(counts[7]), lo=geom[0:3], h=geom[3:6],
                     hi=geom[6:9], c0=geom[9:12], s0=margin[0], rmin=margin[1], rmax=margin[2], d_near=margin[3],
                     delta_g=np.float32(dg.value), cells=cells, entries=entries, index=index)
 
@@ -72,14 +72,15 @@ def test_structure(name):
     c = np.asarray(sph["center"], np.float64)
     r = np.abs(np.asarray(sph["radius"], np.float64))
     cells, entries, index = g["cells"], g["entries"], g["index"]
-    first, groups = (cells & 0xFFFFFF).astype(np.int64), (cells >> 24).astype(np.int64)
-    # cell records tile the gridded part of the entry array, in cell order, four entries per group
-    assert np.array_equal(first, np.concatenate([[0], np.cumsum(groups)[:-1]]))
-    assert 4 * groups.sum() == g["n_cell_entries"] and groups.max() == g["max_groups"] and (groups > 0).sum() == g["nonempty"]
-    assert g["n_entries"] % 4 == 0 and g["n_entries"] >= g["n_cell_entries"] + g["n_always"]
-    # entries are exact copies of the list records; padding can never pass the literal test
+    first, count = (cells & 0xFFFFFF).astype(np.int64), (cells >> 24).astype(np.int64)
+    # cell records tile the gridded part of the entry array, in cell order, without padding
+    assert np.array_equal(first, np.concatenate([[0], np.cumsum(count)[:-1]]))
+    assert count.sum() == g["n_cell_entries"] and count.max() == g["max_entries"] and (count > 0).sum() == g["nonempty"]
+    assert (g["n_entries"] - g["n_cell_entries"]) % 4 == 0 and g["n_entries"] >= g["n_cell_entries"] + g["n_always"]
+    # entries are exact copies of the list records; padding (only behind the always-tested spheres)
+    # can never pass the literal test
     real = index != PAD
-    assert np.all(np.isneginf(entries[~real, 3]))
+    assert real[:g["n_cell_entries"]].all() and np.all(np.isneginf(entries[~real, 3]))
     cs = np.asarray(sph["center"], np.float32)
     rr = np.asarray(sph["radius"], np.float32)
     assert np.array_equal(entries[real, :3], cs[index[real]])
@@ -104,9 +105,8 @@ def test_structure(name):
     # registration: a sphere is an entry of EVERY cell its box inflated by delta_g touches
     lo, h, nn = g["lo"].astype(np.float64), g["h"].astype(np.float64), g["n"]
     member = {}
-    for cell in np.nonzero(groups)[0]:
-        ids = index[4 * first[cell]:4 * (first[cell] + groups[cell])]
-        member[int(cell)] = set(ids[ids != PAD].tolist())
+    for cell in np.nonzero(count)[0]:
+        member[int(cell)] = set(index[first[cell]:first[cell] + count[cell]].tolist())
     rng = np.random.default_rng(0)
     for i in rng.choice(gridded, min(len(gridded), 400), replace=False):
         a = np.clip(np.floor((c[i] - r[i] - float(g["delta_g"]) - lo) / h), 0, nn - 1).astype(np.int64)
@@ -119,7 +119,7 @@ def test_structure(name):
     assert np.all(c[gridded] - r[gridded, None] - float(g["delta_g"]) >= lo - 1e-9)
     assert np.all(c[gridded] + r[gridded, None] + float(g["delta_g"]) <= g["hi"].astype(np.float64) + 1e-9)
     # cells of about one sphere each, a bounded number of copies
-    assert g["n_cell_entries"] <= 16 * len(gridded) + 64
+    assert g["n_cell_entries"] <= 8 * len(gridded) + 64
 
 
 def test_giants_and_big_spheres_are_tested_for_every_ray():
@@ -249,7 +249,7 @@ def walk(g, o, d, sph):
     bnd = fma(f32(cell3 + pos_dir), np.broadcast_to(g["h"][None, :], d.shape), np.broadcast_to(g["lo"][None, :], d.shape))
     tm = np.maximum(f32(f32(bnd - o) * inv), tn[:, None])
     rem = np.where(pos_dir, nn[None, :] - 1 - cell3, cell3) + 1
-    first, groups = (g["cells"] & 0xFFFFFF).astype(np.int64), (g["cells"] >> 24).astype(np.int64)
+    first, count = (g["cells"] & 0xFFFFFF).astype(np.int64), (g["cells"] >> 24).astype(np.int64)
     for _ in range(int(nn.sum()) + 4):
         rays = np.nonzero(active)[0]
         if not len(rays):
@@ -264,13 +264,12 @@ def walk(g, o, d, sph):
         rem[rays, ax] -= 1
         out = rem[rays, ax] == 0
         cell3[rays, ax] += np.where(pos_dir[rays, ax], 1, -1)
-        # all groups of the cell
-        gmax = int(groups[cidx].max()) if len(cidx) else 0
-        for gi in range(gmax):
-            sel = groups[cidx] > gi
-            for k in range(4):
-                test_entries(rays[sel], 4 * (first[cidx[sel]] + gi) + k)
-            looked[rays[sel]] += 4
+        # all entries of the cell
+        cmax = int(count[cidx].max()) if len(cidx) else 0
+        for k in range(cmax):
+            sel = count[cidx] > k
+            test_entries(rays[sel], first[cidx[sel]] + k)
+            looked[rays[sel]] += 1
         done = out | (closest[rays] < t_exit)
         active[rays[done]] = False
     return closest, hit, looked, literal
@@ -301,5 +300,5 @@ def test_walk_returns_the_pair_hit_world_returns(name):
     # (`clumps` is the grid's bad case — a dense clump inside one cell of a sparse field; PT_GEOM_AUTO
     # measures and keeps the hierarchy there)
     if len(sph) >= 100 and name != "clumps":
-        assert total_looked < 0.2 * 4 * n_rays * len(sph)
+        assert total_looked < 0.1 * 4 * n_rays * len(sph)
     assert total_lit < 0.2 * 4 * n_rays
