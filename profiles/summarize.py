@@ -28,9 +28,10 @@ for f in glob.glob(os.path.join(d, "kt_configs", "**", "*_kernel_trace.csv"), re
     rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("pt_trace")]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     for r in rows:
-        print("  %-32s %9.3f ms  grid %s x wg %s  lds %s B  vgpr %s" % (
-            r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size", "?"),
-            r.get("Workgroup_Size", "?"), r.get("LDS_Block_Size", "?"), r.get("VGPR_Count", "?")))
+        print("  %-32s %9.3f ms  grid %s threads in workgroups of %s  lds %s B  vgpr %s+%s sgpr %s" % (
+            r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size_X", "?"),
+            r.get("Workgroup_Size_X", "?"), r.get("LDS_Block_Size", "?"), r.get("VGPR_Count", "?"),
+            r.get("Accum_VGPR_Count", "?"), r.get("SGPR_Count", "?")))
 for f in glob.glob(os.path.join(d, "kt_configs.log")):
     print("== tools/config_sweep.py output under the profiler")
     for line in open(f):

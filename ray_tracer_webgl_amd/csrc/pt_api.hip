@@ -83,6 +83,8 @@ struct pt_ctx {
   size_t grid_cell_cap = 0, grid_entry_cap = 0;
   ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
   int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
+  unsigned long long* d_wave_log = nullptr;  // measuring twins: per-wave {start, queue dry, end}
+  size_t wave_log_cap = 0, wave_log_n = 0;
   uint32_t carry_lanes = 12;
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
@@ -290,6 +292,7 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_bvh_nodes32) (void)hipFree(c->d_bvh_nodes32);
   if (c->d_bvh_slots) (void)hipFree(c->d_bvh_slots);
   if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
+  if (c->d_wave_log) (void)hipFree(c->d_wave_log);
   if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
   if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
   if (c->d_grid_index) (void)hipFree(c->d_grid_index);
@@ -772,12 +775,12 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   // Items a wave reserves per queue atomic.  Items are numbered tile-major, so a reservation is
   // also a run of neighbouring pixels: big reservations keep a wave's lanes on one tile (more
   // coherent walks, fewer atomics), small ones deal the tail of a short launch finely.
-  // Measured on config 2 (hierarchy walk; 32 / 64 / 128 / 256 items): 238.3 / 233.2 / 230.3 /
-  // 230.2 ms at 16 passes per launch (84 items per resident lane), 63.1 / 62.0 / 62.3 / 75.3 ms at
-  // 4 passes (21), 37.3 / 39.9 ms at 2 passes (10); the list walks move by < 1 %.
+  // Measured on config 2, grid walk, 64 passes of 16 spp: the whole frame (225 items per resident
+  // lane) 153.6 / 149.9 / 148.0 / 147.3 ms with 64 / 128 / 256 / 512 items; one rank's band of eight
+  // (28 items per lane) 24.0 / 22.0 / 21.1 / 21.0 / 21.1 / 21.5 / 22.9 ms with 16 ... 1024.
   {
     unsigned long long lanes = (unsigned long long)c->num_cus * (unsigned)per_cu * block;
-    A.queue_chunk = items >= 64ull * lanes ? 128u : (items >= 16ull * lanes ? 64u : 32u);
+    A.queue_chunk = items >= 192ull * lanes ? 512u : (items >= 64ull * lanes ? 128u : (items >= 16ull * lanes ? 64u : 32u));
 #ifdef PT_DEV_KNOBS
     if (const char* e = getenv("PT_QUEUE_CHUNK")) {
       uint32_t v = (uint32_t)atoi(e);
@@ -790,6 +793,19 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
   if (grid < 1) grid = 1;
 
+  A.wave_log = nullptr;
+  if (c->count_work && (path == PT_GEOM_BVH || path == PT_GEOM_GRID)) { // measuring twin: not a product launch, may allocate
+    const size_t n_waves = (size_t)grid * (block / 64);
+    if (n_waves * 3 > c->wave_log_cap) {
+      if (c->d_wave_log) PT_HIP(c, hipFree(c->d_wave_log));
+      c->d_wave_log = nullptr; c->wave_log_cap = 0;
+      PT_HIP(c, hipMalloc(&c->d_wave_log, n_waves * 3 * sizeof(unsigned long long)));
+      c->wave_log_cap = n_waves * 3;
+    }
+    PT_HIP(c, hipMemsetAsync(c->d_wave_log, 0, n_waves * 3 * sizeof(unsigned long long), c->stream));
+    c->wave_log_n = n_waves;
+    A.wave_log = c->d_wave_log;
+  }
   // inside a stream capture (hipGraph) nothing may synchronise and timing events are
   // meaningless: skip the event pair, the launch sequence itself is capture-safe
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -853,6 +869,24 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 
 PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
 
+
+extern "C" __attribute__((visibility("default"))) long pt_debug_counters(pt_ctx* c, unsigned long long* out, size_t cap) {
+  if (!c || !out) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
+  const size_t n = cap < (size_t)PT_CTR_COUNT ? cap : (size_t)PT_CTR_COUNT;
+  if (hipMemcpy(out, c->d_counters, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long)n;
+}
+
+// Dev diagnostics of the measuring twins: per wave {start, queue dry (0 = never saw it dry), end}
+// of the last counted launch, in 100 MHz ticks.  Returns the number of waves, or < 0.
+extern "C" __attribute__((visibility("default"))) long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_waves) {
+  if (!c || !c->d_wave_log || !out) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
+  const size_t n = c->wave_log_n < cap_waves ? c->wave_log_n : cap_waves;
+  if (hipMemcpy(out, c->d_wave_log, n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long)n;
+}
 
 PT_API int pt_synchronize(pt_ctx* c) {
   if (!c) return PT_ERR_INVALID;

@@ -71,6 +71,7 @@ struct PtKernelArgs {
   float grid_r2_near;              // rays with |o - c0|^2 <= this ((0.9999 d_near - s0)^2) walk the cells
   float grid_lo_n[3], grid_hi_n[3];  // [lo, hi] widened by 1e-6 d_near: the entry slab test of those rays
   uint32_t lds_scene_bytes;        // dynamic LDS taken by the staged scene; the parked path state follows
+  unsigned long long* wave_log;    // COUNT twins only (NULL otherwise): per wave {start, queue dry, end} in 100 MHz ticks
   uint32_t long_item_segments;     // waves holding an item older than this get issue priority (6 x spp: ~1.6x the mean item)
   uint32_t carry_lanes;            // the walk moves on when fewer lanes than this (and less than half) still walk
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
@@ -81,7 +82,7 @@ struct PtKernelArgs {
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
 };
 
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_COUNT = 64 };
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.

@@ -322,6 +322,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   bool gactive = false;
 
   // executed-work tallies of the COUNT twin (wave-uniform)
+  unsigned long long t_wave_start = 0, t_wave_dry = 0;
+  uint32_t tb_bin = 0xffffffffu, tb_acc = 0;
+  if constexpr (COUNT) t_wave_start = __builtin_amdgcn_s_memrealtime();
   uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
            n_carried = 0;
 #define PT_COUNT(IT, LN, MASK) do { if constexpr (COUNT) { IT++; LN += (uint32_t)__popcll(MASK); } } while (0)
@@ -365,6 +368,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
         base = __shfl(base, 0);
         if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
+          if constexpr (COUNT) { if (t_wave_dry == 0) t_wave_dry = __builtin_amdgcn_s_memrealtime(); }
           if (need) exhausted = true;
           continue;
         }
@@ -1090,6 +1094,14 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // ---- shade: static/shader.frag:304-335 (carried lanes are not there yet) --------------------
     const bool shade = alive && !carried;
     seg_count += (uint32_t)__popcll(pt_ballot(shade));
+    if constexpr (COUNT) { // segments per time bin (dev diagnostics: where in a launch does the rate sag?)
+      const uint32_t bin = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> 16) & 63u;
+      if (bin != tb_bin) {
+        if (lane == 0 && tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
+        tb_bin = bin; tb_acc = 0;
+      }
+      tb_acc += (uint32_t)__popcll(pt_ballot(shade));
+    }
     if (shade) {
       item_segs++;
       bool finished = false; // this camera path is over
@@ -1212,10 +1224,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       atomicAdd(&A.counters[PT_CTR_WORK + 5], (unsigned long long)n_exact_ln);
       atomicAdd(&A.counters[PT_CTR_WORK + 6], (unsigned long long)n_steps);
       atomicAdd(&A.counters[PT_CTR_WORK + 7], (unsigned long long)n_carried);
+      if (tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
+      if (A.wave_log) {
+        unsigned long long* wl = A.wave_log + 3ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        wl[0] = t_wave_start; wl[1] = t_wave_dry; wl[2] = __builtin_amdgcn_s_memrealtime();
+      }
     }
   }
   (void)n_walk_it; (void)n_walk_ln; (void)n_leaf_it; (void)n_leaf_ln; (void)n_exact_it; (void)n_exact_ln;
-  (void)n_steps; (void)n_carried; (void)tmx; (void)tmy; (void)tmz; (void)t_exit; (void)cell; (void)rem;
+  (void)n_steps; (void)n_carried; (void)t_wave_start; (void)t_wave_dry; (void)tb_bin; (void)tb_acc; (void)tmx; (void)tmy; (void)tmz; (void)t_exit; (void)cell; (void)rem;
   (void)pend; (void)gactive; (void)cur; (void)l0; (void)l1; (void)l2; (void)l3; (void)l_cnt; (void)q0; (void)q1;
   (void)q2; (void)q3; (void)q_cnt; (void)closest_w;
 #undef PT_COUNT

@@ -1,0 +1,56 @@
+"""Dev tool: when do the waves of a launch start, see the queue dry, and end?  (measuring twin)
+
+    python tools/wave_log.py [ranks] [passes] [spp]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ray_tracer_webgl_amd import abi, dist as ptdist, scenes  # noqa: E402
+from ray_tracer_webgl_amd.tracer import PathTracer  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+sc = scenes.config2(1920, 1080, spp, passes, 50)
+p = sc.params.copy()
+p.band_rows, p.band_index, p.band_count = ptdist.band_of(0, n, 4)
+pt = PathTracer(1920, 1080)
+pt.set_spheres(sc.spheres)
+pt.set_params(p)
+pt.reserve_passes(passes)
+pt.set_geometry_path(abi.PT_GEOM_GRID)
+for _ in range(2):
+    pt.reset()
+    pt.render_passes(passes)
+pt.reset()
+pt.set_count_work(True)
+pt.render_passes(passes)
+st = pt.stats()
+buf = np.zeros((20000, 3), np.uint64)
+pt.lib.pt_debug_wave_log.restype = C.c_long
+pt.lib.pt_debug_wave_log.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+k = pt.lib.pt_debug_wave_log(pt._ctx, buf.ctypes.data_as(C.c_void_p), len(buf))
+w = buf[:k].astype(np.float64) * 1e-5  # ms
+t0 = w[:, 0].min()
+start, dry, end = w[:, 0] - t0, np.where(w[:, 1] > 0, w[:, 1] - t0, np.nan), w[:, 2] - t0
+T = end.max()
+print("%d waves, kernel %.2f ms (events %.2f ms); starts within %.3f ms; queue dry first seen at %.2f ms (median %.2f)"
+      % (k, T, st.render_kernel_ms, start.max(), np.nanmin(dry), np.nanmedian(dry)))
+for q in (0.5, 1.0, 1.5, 2.0, 3.0, 4.0):
+    print("  waves still running %.1f ms before the end: %5d of %d" % (q, int((end > T - q).sum()), k))
+print("  wave end times: median %.2f, 90 %% %.2f, 99 %% %.2f, max %.2f" % (np.median(end), np.quantile(end, 0.9), np.quantile(end, 0.99), T))
+lost = (T - end).sum() / (T * k)
+print("  wave-time lost to the drain (sum of (T - end) / (T x waves)): %.3f" % lost)
+ctr = np.zeros(128, np.uint64)
+pt.lib.pt_debug_counters.restype = C.c_long
+pt.lib.pt_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+pt.lib.pt_debug_counters(pt._ctx, ctr.ctypes.data_as(C.c_void_p), 128)
+bins = ctr[64:128].astype(np.float64)
+first = int((buf[:k, 0].min() >> np.uint64(16)) & np.uint64(63))
+order = [(first + j) % 64 for j in range(64)]
+print("  segments per 0.655 ms bin from the first wave's start (Gray/s):")
+print("   " + " ".join("%.1f" % (bins[b] / 0.65536e-3 / 1e9) for b in order if bins[b] > 0))
