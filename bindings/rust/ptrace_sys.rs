@@ -69,6 +69,7 @@ impl PtParams {
             render_count: s.render_count as i32, should_average: s.should_average as i32,
             last_frame_weight: s.last_frame_weight, background_mode: 0,
             band_rows: 8, band_index: 0, band_count: 1,
+            time_step: 0.0, first_pass: 0,   // one pass per frame at u_time = now, as the reference renders
         }
     }
 }
