@@ -274,6 +274,7 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                         reinterpret_cast<const void*>(pt_trace_kernel_grid_gmem), reinterpret_cast<const void*>(pt_trace_kernel_bvh_count),
                         reinterpret_cast<const void*>(pt_trace_kernel_grid_count), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count)})
     (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
+  (void)hipGetLastError(); // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
   *out = c;
@@ -746,7 +747,10 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       const size_t l = scene + (size_t)PT_PARK_STRIDE * 4 * b;
       if (l > lds_max) continue;
       int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) continue;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) {
+        (void)hipGetLastError(); // a size this kernel cannot run at: not an error of this call
+        continue;
+      }
       const int waves = n * (int)(b / 64);
       if (waves > best_waves) { best_waves = waves; bvh_block = b; }
     }
