@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-list-walk --no-work-count"
+BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-work-count"   # keeps the list-walk leg: the scalar list kernel is in the same trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
 # the other BASELINE configs (one launch each after pt_tune): kernel trace only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_configs -- python3 tools/config_sweep.py config3 config4 config5 default > $OUT/kt_configs.log 2>&1

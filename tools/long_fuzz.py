@@ -8,7 +8,9 @@ from ray_tracer_webgl_amd.tracer import render_scene
 from test_gpu_fuzz import random_scene
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-bvh = len(sys.argv) > 3 and sys.argv[3] == "bvh"  # force the hierarchy walk on scenes that get a tree
+bvh = len(sys.argv) > 3 and sys.argv[3] in ("bvh", "grid")  # force a walk kernel on scenes that get a structure
+grid = len(sys.argv) > 3 and sys.argv[3] == "grid"
+used = 0
 bad = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
@@ -20,13 +22,20 @@ for seed in range(lo, hi):
     sc = random_scene(rng, n, width, height, spp, depth, passes)
     path = int(rng.integers(0, 4))
     if bvh:
-        path = 3
+        path = 4 if grid else 3
+        if grid and seed % 2 == 0:  # mostly small spheres: what a grid is for (the rest: wild radii, many always-tested)
+            small = rng.random(n) < 0.9
+            sc.spheres["radius"][small] = (np.sign(sc.spheres["radius"][small]) * rng.uniform(0.05, 0.4, small.sum())).astype(np.float32)
+        if grid and seed % 5 == 0:  # a flat field: one layer of cells
+            sc.spheres["center"][:, 1] = np.float32(0.3)
         if seed % 3 != 1:  # spread the field out so that the tree has something to cull
             sc.spheres["center"] *= np.float32(rng.choice([2.0, 4.0, 15.0, 100.0]))
         if seed % 7 == 0:  # and far from the origin: the margin works in the frame of the scene
             sc.spheres["center"] += np.float32(rng.choice([50.0, 3000.0]))
             sc.params.camera_origin[0] += float(sc.spheres["center"][0][0]) * 0  # camera stays: distant views
+    from ray_tracer_webgl_amd.tracer import PathTracer
     t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=path)
+    used += int(t.stats().geometry_path == path)
     ref, seg = oracle.render(sc.spheres, sc.params, passes)
     ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and t.stats().segments == seg
     if not ok:
@@ -35,4 +44,4 @@ for seed in range(lo, hi):
     t.close()
     if seed % 50 == 0:
         print("seed", seed, "ok so far, bad =", bad, flush=True)
-print("done", lo, hi, "bad =", bad)
+print("done", lo, hi, "bad =", bad, "forced path really used:", used)
