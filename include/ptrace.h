@@ -54,7 +54,7 @@ enum {
  *          at: boxes are inflated by a per-ray margin that covers the rounding of the literal
  *          test, so only spheres that cannot pass it are skipped (regular scenes of >= 16
  *          spheres; a scene without a hierarchy falls back to SCALAR)
- *   GRID   a uniform grid built by pt_set_spheres (cells of about one sphere each, 3D-DDA walk,
+ *   GRID   a uniform grid built by pt_set_spheres (cells of about two spheres each, 3D-DDA walk,
  *          entries registered with a margin that covers the rounding of the literal test and of
  *          the walk): a ray looks at the entries of the cells it passes through, in order, and
  *          stops once its closest root lies before the current cell's exit.  The better
@@ -77,6 +77,8 @@ enum {
   PT_OPT_CARRY_LANES = 3, /* walk kernels: move on to shading when fewer lanes than this (and less than half
                              of the wave) are still walking; the stragglers continue in the next wave step.
                              Scheduling only — images do not depend on it.  0 = lockstep.  Default 12. */
+  PT_OPT_REFILL_MIN = 4,  /* lanes of a busy wave that wait for a new work item before the (wave-wide) item
+                             decode runs for them.  Scheduling only.  1 = refill at once.  Default 4. */
 };
 
 /* ---- background modes ----------------------------------------------------------------------- */

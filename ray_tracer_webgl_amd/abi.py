@@ -29,7 +29,7 @@ PT_BG_SKY = 0
 PT_BG_BLACK = 1
 
 PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH, PT_GEOM_GRID = 0, 1, 2, 3, 4
-PT_OPT_GEOMETRY_PATH, PT_OPT_COUNT_WORK, PT_OPT_CARRY_LANES = 1, 2, 3
+PT_OPT_GEOMETRY_PATH, PT_OPT_COUNT_WORK, PT_OPT_CARRY_LANES, PT_OPT_REFILL_MIN = 1, 2, 3, 4
 PT_TIME_STEP_DECORRELATED = 0.3618034  # include/ptrace.h
 GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh", 4: "grid"}
 

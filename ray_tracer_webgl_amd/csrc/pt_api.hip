@@ -86,6 +86,7 @@ struct pt_ctx {
   unsigned long long* d_wave_log = nullptr;  // measuring twins: per-wave {start, queue dry, end}
   size_t wave_log_cap = 0, wave_log_n = 0;
   uint32_t carry_lanes = 12;
+  uint32_t refill_min = 4;
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -668,6 +669,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   uint32_t bvh_block = 0;
   A.coop_max_live = 16;
   A.carry_lanes = c->carry_lanes;
+  A.refill_min = c->refill_min;
   A.long_item_segments = 6u * (uint32_t)p.samples_per_pixel;
 #ifdef PT_DEV_KNOBS
   if (const char* e = getenv("PT_LONG_ITEM")) A.long_item_segments = (uint32_t)atoi(e);
@@ -996,6 +998,11 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   }
   if (key == PT_OPT_COUNT_WORK) { // measuring twin of the walk kernels (PtStats.work); slower, never timed
     c->count_work = value ? 1 : 0;
+    return PT_OK;
+  }
+  if (key == PT_OPT_REFILL_MIN) { // scheduling only, never results
+    if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: refill min %d", value);
+    c->refill_min = (uint32_t)value;
     return PT_OK;
   }
   if (key == PT_OPT_CARRY_LANES) { // 0 = lockstep to the last lane; scheduling only, never results

@@ -359,10 +359,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // The wave reserves A.queue_chunk consecutive items from the global queue with ONE atomic
     // (a memory-side atomic moves 64 B, so per-item atomics would dominate the kernel's HBM
     // traffic) and deals them to its lanes from a wave-uniform local pool.
+    // Lanes that finish an item wait until a few of them can be refilled together: the item decode
+    // below costs ~115 VALU instructions for the whole wave whether one lane needs it or sixty,
+    // and with 16-spp items about one lane per wave step does.  A wave that is mostly idle (the
+    // drain of the launch, or its start) refills at once.
     for (;;) {
       bool need = !alive && !exhausted;
       unsigned long long mask = pt_ballot(need);
       if (mask == 0ull) break;
+      if ((uint32_t)__popcll(mask) < K.refill_min && (uint32_t)__popcll(pt_ballot(alive)) >= 32u) break;
       if (pool_next == pool_end) { // wave-uniform
         unsigned long long base = 0;
         if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);

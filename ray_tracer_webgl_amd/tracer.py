@@ -108,6 +108,11 @@ class PathTracer:
         still walk; 0 = lockstep.  Scheduling only: images do not depend on it."""
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_CARRY_LANES, int(n)))
 
+    def set_refill_min(self, n):
+        """Lanes of a busy wave that wait for a new item before the item decode runs (1 = at once).
+        Scheduling only: images do not depend on it."""
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_REFILL_MIN, int(n)))
+
     def tune(self, n_passes):
         """Settle PT_GEOM_AUTO now (one cold + one untimed launch of n_passes passes per usable
         path); clears the accumulation."""

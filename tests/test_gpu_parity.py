@@ -770,6 +770,28 @@ def test_carrying_stragglers_is_scheduling_only(ora, path):
     t.close()
 
 
+@pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_GRID])
+def test_deferred_refill_is_scheduling_only(ora, path):
+    """PT_OPT_REFILL_MIN: a busy wave runs the item decode only once a few lanes wait for an item.
+    Which step a lane gets its next item in cannot change what the item computes."""
+    sc = scenes.config2(160, 90, 2, 3, 50)
+    ref, seg = ora.render(sc.spheres, sc.params, 3)
+    for lanes in (1, 4, 16, 64):
+        t = PathTracer(160, 90)
+        t.set_geometry_path(path)
+        t.set_refill_min(lanes)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.reserve_passes(3)
+        t.render_passes(3)
+        assert_bit_equal(t.accum(), ref, "refill_min %d" % lanes)
+        assert t.stats().segments == seg
+        t.close()
+    t = PathTracer(8, 8)
+    assert t.lib.pt_set_option(t._ctx, abi.PT_OPT_REFILL_MIN, 0) == abi.PT_ERR_INVALID
+    t.close()
+
+
 def test_pt_tune_settles_the_path_and_leaves_a_clean_context(ora):
     sc = scenes.config2(128, 72, 4, 2, 50)
     t = PathTracer(128, 72)

@@ -543,3 +543,36 @@ def test_mirror_pixels_of_the_reference_screenshot(ora):
         got = np.sqrt(np.array(col[:], dtype=np.float64)) * 255.0
         worst = max(worst, float(np.abs(got - np.array(px["rgb"], dtype=np.float64)).max()))
     assert worst <= 2.0, worst
+
+
+def test_pass_times_follow_time_step_and_first_pass(ora):
+    """PtParams.time_step / first_pass (include/ptrace.h): pass p of a call renders with
+    u_time = time + float(first_pass + p) * time_step — one fp32 multiply, then one fp32 add — so a
+    frame rendered as several calls has the bits of one call; a step of 0 means 1."""
+    sc = scenes.default_scene(48, 27, spp=2, max_depth=8)
+    p = sc.params.copy()
+    p.time, p.time_step = 2.5, abi.PT_TIME_STEP_DECORRELATED
+    whole, seg = ora.render(sc.spheres, p, 5)
+    # pass by pass, with the time spelled out in numpy float32
+    acc = np.zeros_like(whole)
+    total = 0
+    for k in range(5):
+        q = sc.params.copy()
+        q.time = float(np.float32(2.5) + np.float32(k) * np.float32(abi.PT_TIME_STEP_DECORRELATED))
+        q.time_step = 1.0
+        a, s = ora.render(sc.spheres, q, 1)
+        acc = acc + a
+        total += s
+    assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32)) and total == seg
+    # two calls: 2 passes, then 3 more starting at first_pass = 2
+    a1, s1 = ora.render(sc.spheres, p, 2)
+    q = p.copy()
+    q.first_pass = 2
+    a2, s2 = ora.render(sc.spheres, q, 3, accum=a1.copy())
+    assert np.array_equal(a2.view(np.uint32), whole.view(np.uint32)) and s1 + s2 == seg
+    # step 0 is step 1
+    z = sc.params.copy()
+    z.time_step = 0.0
+    o = sc.params.copy()
+    o.time_step = 1.0
+    assert np.array_equal(ora.render(sc.spheres, z, 3)[0], ora.render(sc.spheres, o, 3)[0])

@@ -24,6 +24,8 @@ for path, carry in variants:
     pt = PathTracer(p.width, p.height)
     pt.set_geometry_path(path)
     pt.set_carry_lanes(carry)
+    if os.environ.get("AB_REFILL_MIN"):
+        pt.set_refill_min(int(os.environ["AB_REFILL_MIN"]))
     pt.set_spheres(sc.spheres)
     pt.set_params(p)
     pt.reserve_passes(passes)
