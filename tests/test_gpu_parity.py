@@ -676,9 +676,14 @@ def test_sphere_list_beyond_lds_capacity(ora):
     global copy (pt_trace_kernel_scalar) is used instead.  Window-checked against the oracle."""
     sc = scenes.config5(160, 90, 2, 1, 20, n=12000)
     assert len(sc.spheres) == 12001
-    t, got, ref = _check_scene(ora, sc, window=(60, 84, 30, 46))
+    t, got, ref = _check_scene(ora, sc, window=(60, 84, 30, 46), geometry_path=abi.PT_GEOM_LDS)  # falls back
     assert t.stats().geometry_path == abi.PT_GEOM_SCALAR
     t.close()
+    # left to itself PT_GEOM_AUTO does not even try the list walks on a structured scene this size
+    t2, got2 = render_scene(sc)
+    assert t2.stats().geometry_path in (abi.PT_GEOM_BVH, abi.PT_GEOM_GRID)
+    assert_bit_equal(got2, got, "culling structure vs the list walk, whole frame")
+    t2.close()
 
 
 @pytest.mark.parametrize("path", [abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR, abi.PT_GEOM_BVH, abi.PT_GEOM_GRID, abi.PT_GEOM_AUTO])
