@@ -299,6 +299,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 
   uint32_t seg_count = 0; // wave-uniform tally (samples are derived on the host: pixels * spp * passes)
   uint32_t pool_next = 0, pool_end = 0;     // wave-uniform: this wave's reserved queue items
+  uint32_t refill_waited = 0;               // wave-uniform: steps the waiting lanes have been put off
 
   // ---- walk state that survives a wave step (walk kernels) ------------------------------------
   // The 64 walks of a wave step differ in length, and every loop runs for its longest lane:
@@ -367,7 +368,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       bool need = !alive && !exhausted;
       unsigned long long mask = pt_ballot(need);
       if (mask == 0ull) break;
-      if ((uint32_t)__popcll(mask) < K.refill_min && (uint32_t)__popcll(pt_ballot(alive)) >= 32u) break;
+      if ((uint32_t)__popcll(mask) < K.refill_min && (uint32_t)__popcll(pt_ballot(alive)) >= 32u && refill_waited < 8u) {
+        refill_waited++; // ... but not for long: with long items the next lane may be hundreds of steps away
+        break;
+      }
+      refill_waited = 0;
       if (pool_next == pool_end) { // wave-uniform
         unsigned long long base = 0;
         if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
