@@ -83,7 +83,7 @@ struct PtKernelArgs {
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
 };
 
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_PHASES = 24, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.

@@ -300,6 +300,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   uint32_t seg_count = 0; // wave-uniform tally (samples are derived on the host: pixels * spp * passes)
   uint32_t pool_next = 0, pool_end = 0;     // wave-uniform: this wave's reserved queue items
   uint32_t refill_waited = 0;               // wave-uniform: steps the waiting lanes have been put off
+  uint32_t pool_tp0 = 0, pool_split = 0, pool_tile0 = 0, pool_tile1 = 0; // wave-uniform: the reservation's tile(s)
 
   // ---- walk state that survives a wave step (walk kernels) ------------------------------------
   // The 64 walks of a wave step differ in length, and every loop runs for its longest lane:
@@ -329,6 +330,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
            n_carried = 0;
 #define PT_COUNT(IT, LN, MASK) do { if constexpr (COUNT) { IT++; LN += (uint32_t)__popcll(MASK); } } while (0)
+  // phase clock of the COUNT twins (shader cycles, s_memtime): where a wave's time goes
+  //   0 refill  1 camera ray  2 set-up + always-tested  3 advance / node loops  4 leaf + exact  5 literal + rest  6 shade
+  unsigned long long ph_t[7] = {0, 0, 0, 0, 0, 0, 0}, ph_mark = 0;
+  if constexpr (COUNT) ph_mark = __builtin_amdgcn_s_memtime();
+#define PT_PHASE(k) do { if constexpr (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_t[k] += now_ - ph_mark; ph_mark = now_; } } while (0)
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
   auto start_sample = [&]() {
@@ -385,6 +391,13 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         pool_next = (uint32_t)base;
         unsigned long long end = base + A.queue_chunk;
         pool_end = end < (unsigned long long)A.n_items ? (uint32_t)end : A.n_items;
+        // a reservation no longer than one tile's items touches at most two tiles: look their numbers
+        // up once, here, instead of one dependent global load per lane in every refill
+        pool_tp0 = div_(pool_next, K.div_per_tile.m, K.div_per_tile.s1, K.div_per_tile.s2);
+        pool_split = (pool_tp0 + 1u) * (64u * K.n_passes);
+        const uint32_t n_tiles_w = K.tiles_x * K.tiles_y;
+        pool_tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)K.tile_order[pool_tp0]);
+        pool_tile1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)K.tile_order[pool_tp0 + 1u < n_tiles_w ? pool_tp0 + 1u : pool_tp0]);
       }
       const uint32_t avail = pool_end - pool_next;
       const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -394,9 +407,16 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       if (need && rank < avail) {
         uint32_t item = pool_base + rank;
         uint32_t per_tile = 64u * K.n_passes;
-        uint32_t tile_pos = div_(item, K.div_per_tile.m, K.div_per_tile.s1, K.div_per_tile.s2);
+        uint32_t tile_pos, tile; // heaviest tiles are dealt first (tile_order)
+        if (K.queue_chunk <= per_tile) { // wave-uniform
+          const bool second = item >= pool_split;
+          tile_pos = pool_tp0 + (second ? 1u : 0u);
+          tile = second ? pool_tile1 : pool_tile0;
+        } else {
+          tile_pos = div_(item, K.div_per_tile.m, K.div_per_tile.s1, K.div_per_tile.s2);
+          tile = K.tile_order[tile_pos];
+        }
         uint32_t rem_i = item - tile_pos * per_tile;
-        uint32_t tile = K.tile_order[tile_pos]; // heaviest tiles are dealt first
         uint32_t pass = rem_i >> 6, l = rem_i & 63u;
         uint32_t ty = div_(tile, K.div_tiles_x.m, K.div_tiles_x.s1, K.div_tiles_x.s2), tx = tile - ty * K.tiles_x;
         uint32_t px = tx * 8u + (l & 7u), ly = ty * 8u + (l >> 3);
@@ -427,12 +447,14 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         // an item that falls outside the image (edge tile) is simply dropped
       }
     }
+    PT_PHASE(0);
     // one copy of the camera-ray code per step serves both kinds of lanes: those that just
     // pulled an item and those whose previous path ended in the last step
     if (alive && new_path) {
       start_sample();
       new_path = false;
     }
+    PT_PHASE(1);
     unsigned long long live = pt_ballot(alive);
     if (live == 0ull) break; // every lane is exhausted: the queue is dry
     if constexpr (COUNT) n_steps++;
@@ -824,7 +846,15 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         const uint32_t n_grp = (A.n_outliers + 3u) >> 2;
         for (uint32_t gi = 0; gi < n_grp; gi++) {
           const uint32_t base = n_cell_entries + 4u * gi;
-          const f4v e0 = c_slots[base], e1 = c_slots[base + 1u], e2 = c_slots[base + 2u], e3 = c_slots[base + 3u];
+          // wave-uniform index: an LDS broadcast where the entries are staged, scalar loads otherwise
+          float4 e0, e1, e2, e3;
+          if constexpr (WALK == 4) {
+            e0 = slot_at(base); e1 = slot_at(base + 1u); e2 = slot_at(base + 2u); e3 = slot_at(base + 3u);
+          } else {
+            const f4v s0 = c_slots[base], s1 = c_slots[base + 1u], s2 = c_slots[base + 2u], s3 = c_slots[base + 3u];
+            e0 = make_float4(s0.x, s0.y, s0.z, s0.w); e1 = make_float4(s1.x, s1.y, s1.z, s1.w);
+            e2 = make_float4(s2.x, s2.y, s2.z, s2.w); e3 = make_float4(s3.x, s3.y, s3.z, s3.w);
+          }
           PT_TEST(e0, hb0, cc0, ds0)
           PT_TEST(e1, hb1, cc1, ds1)
           PT_TEST(e2, hb2, cc2, ds2)
@@ -909,6 +939,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
 
+      PT_PHASE(2);
       uint32_t walk_iters = 0;
       for (;;) {
         // advance: a lane without a cell under test looks at the cell it stands in, notes its
@@ -939,6 +970,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             if (out || ((rec >> 24) == 0u && closest < tmin)) gactive = false;
           }
         }
+        PT_PHASE(3);
         const bool has = (pend >> 24) != 0u;
         const unsigned long long m_has = pt_ballot(has);
         if (m_has == 0ull) break; // no cell under test and nobody can move: every walk is over
@@ -964,6 +996,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           // the cell is done: can anything registered only in later cells still win?
           if (has && (pend >> 24) == 0u && closest < t_exit) gactive = false;
         }
+        PT_PHASE(4);
         walk_iters++;
         const unsigned long long m_on = pt_ballot(gactive || (pend >> 24) != 0u);
         if (m_on == 0ull) break;
@@ -1101,6 +1134,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       sample = (int)ps[12]; depth = (int)ps[13];
     }
 
+    PT_PHASE(5);
     // ---- shade: static/shader.frag:304-335 (carried lanes are not there yet) --------------------
     const bool shade = alive && !carried;
     seg_count += (uint32_t)__popcll(pt_ballot(shade));
@@ -1221,6 +1255,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         }
       }
     }
+    PT_PHASE(6);
   }
 
   if (lane == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
@@ -1235,6 +1270,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       atomicAdd(&A.counters[PT_CTR_WORK + 6], (unsigned long long)n_steps);
       atomicAdd(&A.counters[PT_CTR_WORK + 7], (unsigned long long)n_carried);
       if (tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
+      for (int k = 0; k < 7; k++) atomicAdd(&A.counters[PT_CTR_PHASES + k], ph_t[k]);
       if (A.wave_log) {
         unsigned long long* wl = A.wave_log + 3ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
         wl[0] = t_wave_start; wl[1] = t_wave_dry; wl[2] = __builtin_amdgcn_s_memrealtime();
@@ -1242,10 +1278,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     }
   }
   (void)n_walk_it; (void)n_walk_ln; (void)n_leaf_it; (void)n_leaf_ln; (void)n_exact_it; (void)n_exact_ln;
-  (void)n_steps; (void)n_carried; (void)t_wave_start; (void)t_wave_dry; (void)tb_bin; (void)tb_acc; (void)tmx; (void)tmy; (void)tmz; (void)t_exit; (void)cell; (void)rem;
+  (void)n_steps; (void)n_carried; (void)t_wave_start; (void)t_wave_dry; (void)tb_bin; (void)tb_acc; (void)ph_t; (void)ph_mark; (void)tmx; (void)tmy; (void)tmz; (void)t_exit; (void)cell; (void)rem;
   (void)pend; (void)gactive; (void)cur; (void)l0; (void)l1; (void)l2; (void)l3; (void)l_cnt; (void)q0; (void)q1;
   (void)q2; (void)q3; (void)q_cnt; (void)closest_w;
 #undef PT_COUNT
+#undef PT_PHASE
 #undef lane
 }
 

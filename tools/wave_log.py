@@ -54,3 +54,6 @@ first = int((buf[:k, 0].min() >> np.uint64(16)) & np.uint64(63))
 order = [(first + j) % 64 for j in range(64)]
 print("  segments per 0.655 ms bin from the first wave's start (Gray/s):")
 print("   " + " ".join("%.1f" % (bins[b] / 0.65536e-3 / 1e9) for b in order if bins[b] > 0))
+ph = ctr[24:31].astype(np.float64)
+names = ["refill", "camera ray", "set-up + always-tested", "advance / node loops", "leaf + exact", "literal + unpark", "shade"]
+print("  wave-time shares by phase (s_memtime): " + ", ".join("%s %.3f" % (n_, v / ph.sum()) for n_, v in zip(names, ph)))
