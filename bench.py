@@ -9,11 +9,17 @@
            the default 16 steps are exactly the config's 1024 spp "converged frame".  Steps are
            enqueued `--steps-per-launch` at a time through pt_render_passes (one persistent kernel
            launch works through all their (pixel, pass) items from one queue).
-  N > 1    strong scaling: the same frame, rows dealt to ranks in interleaved 8-row bands, no
-           collective while rendering, ONE all_gather of the radiance buffers (RCCL over xGMI)
-           at the end of the timed region.  `python bench.py --gpus N` from a bare shell starts
-           its N ranks itself (the parent never touches the GPU); under torch.distributed.run
-           it uses the ranks it is given.
+  N > 1    the image's rows are dealt to the ranks in interleaved 4-row bands (the path shards by
+           pixel: no collective while rendering), ONE all_gather of the radiance buffers (RCCL over
+           xGMI) at the end of the timed region.  Default `--scaling weak`: per-GPU work is fixed —
+           a rank renders 1/N of the rows for N x 4 passes per step, so a step is N x 64 spp of the
+           whole frame (the same pass seeds a single GPU would use for that many passes; the
+           gathered image is bit-identical to the single-GPU one).  `--scaling strong` keeps the
+           frame fixed (4 passes per step whatever N).  Either way the line carries `fixed_frame`:
+           the config's own 1024-spp frame split over the N ranks, timed after the main region
+           with the same barriers (= the strong-scaling point; `sec_to_converged_frame` is that).
+           `python bench.py --gpus N` from a bare shell starts its N ranks itself (the parent never
+           touches the GPU); under torch.distributed.run it uses the ranks it is given.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the path-tracing kernel against the FP32
 vector peak (the path has no dense contraction and ~1e5 FLOP per HBM byte):
@@ -86,7 +92,8 @@ def spawn_ranks(n):
             p.kill()
             p.wait()
         rc = rc or p.returncode
-    sys.stdout.write(out0 or "")
+    for line in (out0 or "").splitlines():  # stdout carries the JSON line only (gloo chats on stdout)
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return rc
 
@@ -125,6 +132,8 @@ def main():
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--band-rows", type=int, default=4,
                     help="N > 1: rows per interleaved band (4: rank shares of the work within 1 %% of each other at N = 8)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = passes per step grow with N (fixed work per GPU); strong = the same frame for every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-list-walk", action="store_true",
                     help="skip the extra (untimed-region) launch that measures the reference's linear list walk")
@@ -171,7 +180,8 @@ def main():
             dist.init_process_group("gloo")
         ranks_seen = dist.get_world_size()
 
-    pps = max(1, args.passes_per_step)
+    pps_frame = max(1, args.passes_per_step)  # passes per step of the single-GPU workload
+    pps = pps_frame * (world if args.scaling == "weak" else 1)  # passes per step on this rank's rows
     spp_step = args.spp_per_pass * pps
 
     def gather(t):
@@ -201,15 +211,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_steps(k, first_time):
+    def run_steps(k, first_time, pps_use=None, spl_use=None):
+        pps_use = pps_use or pps
         done = 0
         while done < k:
-            n = min(spl, k - done)
+            n = min(spl_use or spl, k - done)
             q = p.copy()
             q.time = float(first_time)
-            q.first_pass = done * pps  # pass j of this launch uses u_time = time + (first_pass + j) * time_step
+            q.first_pass = done * pps_use  # pass j of this launch uses u_time = time + (first_pass + j) * time_step
             pt.set_params(q)
-            pt.render_passes(n * pps)  # asynchronous on torch's current stream
+            pt.render_passes(n * pps_use)  # asynchronous on torch's current stream
             done += n
 
     # warmup (untimed), then clear accumulation and statistics
@@ -239,6 +250,38 @@ def main():
     wall = float(elapsed.item())
     segments = float(sum(float(x[0]) for x in per_rank))
     per_rank_kernel_ms = [round(float(x[1]), 3) for x in per_rank]
+
+    # the config's own frame (1024 spp) split over the ranks: the strong-scaling point.  At N = 1, or
+    # under --scaling strong, the main region already is that workload.
+    fixed_frame = None
+    if world > 1 and args.scaling == "weak":
+        k_ff = max(1, CONVERGED_SPP // (args.spp_per_pass * pps_frame))
+        spl_ff = max(1, min(args.steps_per_launch, k_ff, ppl // pps_frame))  # within the reserved passes
+        pt.reset()
+        run_steps(k_ff, 1000.0, pps_frame, spl_ff)  # settle the tile order for this launch shape
+        gather(pt.accum_tensor)
+        sync_all()
+        pt.reset()
+        sync_all()
+        f0 = time.perf_counter()
+        run_steps(k_ff, 0.0, pps_frame, spl_ff)
+        full = gather(pt.accum_tensor)
+        sync_all()
+        f1 = time.perf_counter()
+        sf = pt.stats()
+        ff = torch.tensor([f1 - f0], dtype=torch.float64, device=cdev)
+        fseg = torch.tensor([float(sf.segments)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ff, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fseg)
+        fixed_frame = {
+            "spp": k_ff * args.spp_per_pass * pps_frame,
+            "sec": round(float(ff.item()), 5),
+            "value": round(float(fseg.item()) / float(ff.item()) / 1e6, 3),
+            "unit": "Mray/s",
+            "scaling": "strong",
+            "note": "same frame as N = 1 (%d launches of <= %d passes over 1/%d of the rows per rank + the gather), "
+                    "barrier + synchronize on both sides, max over ranks" % ((k_ff + spl_ff - 1) // spl_ff, spl_ff * pps_frame, world),
+        }
 
     if rank == 0:
         n_sph = len(sc.spheres)
@@ -409,19 +452,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "config2: Shirley cover scene (%d spheres), %dx%d, %d bounces, %d spp/step (%d passes x %d spp) x %d steps = %d spp"
                             % (n_sph, p.width, p.height, args.max_depth, spp_step, pps, args.spp_per_pass, args.steps, spp_step * args.steps),
-                "partition": "%d rank(s), interleaved %d-row bands, one all_gather at frame end" % (world, band_rows),
+                "partition": "%d rank(s), interleaved %d-row bands, one all_gather at the end of the timed region%s"
+                             % (world, band_rows, "; per-GPU work fixed: 1/%d of the rows x %d passes per step" % (world, pps)
+                                if (world > 1 and args.scaling == "weak") else ""),
                 "steps_per_launch": spl,
                 "passes_per_launch": ppl,
                 "spp_per_pass": args.spp_per_pass,
             },
-            "sec_to_converged_frame": round(wall / args.steps * (CONVERGED_SPP / spp_step), 4),
+            "sec_to_converged_frame": fixed_frame["sec"] if fixed_frame else round(wall / args.steps * (CONVERGED_SPP / spp_step), 4),
+            "fixed_frame": fixed_frame,
             "converged_frame_spp": CONVERGED_SPP,
             "segments": int(segments),
             "nominal_mray_s": round(p.width * p.height * spp_step * args.steps * args.max_depth / wall / 1e6, 1),
