@@ -120,6 +120,111 @@ __device__ __forceinline__ float cbrt_(float x) {
   return (x == 0.0f) ? 0.0f : r;
 }
 
+
+// --------------------------------------------------------------------------------------------
+// Correctly rounded sqrt and division without the range scaling.
+//
+// `__builtin_sqrtf(x)` and `n / b` compile to correctly rounded fp32 results (PT-SPEC relies on
+// that).  The compiler's expansions are, for the division n / b:
+//     b' = v_div_scale(b)  n' = v_div_scale(n)          power-of-two scaling for extreme exponents
+//     y0 = v_rcp(b')  y = fma(fma(-b', y0, 1), y0, y0)
+//     q0 = n' y   q1 = fma(fma(-b', q0, n'), y, q0)   q = v_div_fmas(fma(-b', q1, n'), y, q1)
+//     v_div_fixup(q, b, n)                               zeros, infinities, NaNs, the sign of 0
+// and for the square root: scale by 2^32 below 2^-96, s = v_sqrt, pick s-1ulp / s / s+1ulp by the
+// signs of the two residuals fma(-(s -+ 1ulp), s, x), unscale, pass 0 / inf through.
+// v_div_scale is the identity (and v_div_fmas a plain fma, v_div_fixup the identity) when
+//     b normal, |b| < 2^126, n != 0, |n| >= 2^-103, exponent(n) - exponent(b) < 96, n / b normal,
+// so for such operands div_core() below IS the compiler's sequence, operation for operation, and
+// returns the same correctly rounded quotient — with y computed once per denominator instead of
+// once per division.  Likewise sqrt_core() is the compiler's sequence for x >= 2^-96 (it also
+// returns 0 for 0 and inf for inf: both residual tests are then false).  Callers guard the
+// operand ranges and fall back to the plain operators, wave-uniformly, when any lane is outside
+// (practically never); the guards are stated at each call site.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sqrt_core(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = u2f(f2u(s) - 1u), s_up = u2f(f2u(s) + 1u);
+  const float r_dn = fma_(-s_dn, s, x), r_up = fma_(-s_up, s, x);
+  float r = (0.0f >= r_dn) ? s_dn : s;
+  r = (0.0f < r_up) ? s_up : r;
+  return r;
+}
+__device__ __forceinline__ float rcp_newton(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  return fma_(fma_(-b, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float div_core(float n, float b, float y) {
+  const float q0 = n * y;
+  const float q1 = fma_(fma_(-b, q0, n), y, q0);
+  return fma_(fma_(-b, q1, n), y, q1);
+}
+#ifndef PT_FAST_EXACT
+#define PT_FAST_EXACT 1 // hit_root: unscaled forms under a guard (0: the plain operators)
+#endif
+#ifndef PT_FAST_SQRT
+#define PT_FAST_SQRT 1
+#endif
+#ifndef PT_FAST_NORMAL
+#define PT_FAST_NORMAL 1
+#endif
+// x in [lo, hi) for positive floats lo < hi, false for negative x and NaN: one subtract and one
+// unsigned compare on the bit patterns (which order like the values for positive floats)
+__device__ __forceinline__ bool in_range_bits(float x, float lo, float hi) {
+  return f2u(x) - f2u(lo) < f2u(hi) - f2u(lo);
+}
+// denominators for which 1/b and the exponent-difference conditions hold for every |n| < 2^76
+__device__ __forceinline__ bool div_den_ok(float b) {
+  return in_range_bits(__builtin_fabsf(b), 0x1p-20f, 0x1p20f);
+}
+// per-ray guard word for hit_root: the width of the accepted discriminant range [2^-96, 2^127),
+// or 0 (nothing accepted) when the ray's |d|^2 is no denominator for the fast form
+__device__ __forceinline__ uint32_t hit_root_guard(float a) {
+  return div_den_ok(a) ? f2u(0x1p127f) - f2u(0x1p-96f) : 0u;
+}
+// correctly rounded sqrt for any x (same bits as __builtin_sqrtf)
+__device__ __forceinline__ float sqrt_rn(float x) {
+#if PT_FAST_SQRT
+  float r = sqrt_core(x);
+  const bool odd = !(x >= 0x1p-96f); // tiny, negative, NaN
+  if (__builtin_expect(pt_ballot(odd) != 0ull, 0)) { // (rare)
+    if (odd) r = __builtin_sqrtf(x);
+  }
+  return r;
+#else
+  return __builtin_sqrtf(x);
+#endif
+}
+
+// The exact part of hit_sphere, static/shader.frag:156-161, for a candidate with discriminant
+// disc = fma(-a, c, half_b * half_b) >= 0 (or NaN): the root `v` the shader would test first,
+// replaced by the far root when the near one is below MIN_T.  ya = rcp_newton(a) and
+// guard = hit_root_guard(a), both per ray.
+// Fast form when every lane that is in here has a in [2^-20, 2^20) and 2^-96 <= disc < 2^127.
+// A finite disc means half_b * half_b did not overflow: |half_b| < 2^64, and sqrt(disc) is in
+// [2^-48, 2^64), so both numerators n = -half_b -+ sqrt(disc) have |n| < 2^65; a numerator is
+// either exactly 0 or at least one ulp of a number >= 2^-48 (>= 2^-71 > 2^-103), so every
+// condition above holds for a non-zero n and div_core returns the correctly rounded root.
+// For n == 0 div_core returns a zero, as the division does (its sign is v_div_fixup's business
+// and is never looked at: a root below MIN_T is only compared with MIN_T — a near root is
+// replaced by the far root, a far root rejected).
+__device__ __forceinline__ float hit_root(float half_b, float disc, float a, float ya, uint32_t guard) {
+  float v;
+#if PT_FAST_EXACT
+  const bool odd = f2u(disc) - f2u(0x1p-96f) >= guard;
+  if (__builtin_expect(pt_ballot(odd) == 0ull, 1)) {
+    const float sqrtd = sqrt_core(disc);
+    v = div_core(-half_b - sqrtd, a, ya);
+    if (v < PT_MIN_T) v = div_core(-half_b + sqrtd, a, ya);
+  } else // (rare) the plain operators for the whole wave
+#endif
+  {
+    const float sqrtd = __builtin_sqrtf(disc);
+    v = (-half_b - sqrtd) / a;             // :158
+    if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; // :159-160
+  }
+  return v;
+}
+
 // static/shader.frag:114-121
 __device__ __forceinline__ V3 random_in_unit_sphere(float& seed) {
   float h0, h1, h2;
@@ -128,12 +233,12 @@ __device__ __forceinline__ V3 random_in_unit_sphere(float& seed) {
   float sp, cp;
   sincos2pi(h1, sp, cp);
   float r = cbrt_(h2);
-  float sq = __builtin_sqrtf(fma_(-hx, hx, 1.0f));
+  float sq = sqrt_rn(fma_(-hx, hx, 1.0f));
   return mk(r * (sq * sp), r * (sq * cp), r * hx);
 }
 
 __device__ __forceinline__ V3 normalize3(V3 a) {
-  float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
+  float inv = 1.0f / sqrt_rn(dot3(a, a));
   return mk(a.x * inv, a.y * inv, a.z * inv);
 }
 
@@ -345,7 +450,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     float ua = hash1(seed); // random_in_unit_circle :123-129, consumed even if lens_radius == 0
     float sa, ca;
     sincos2pi(ua, sa, ca);
-    float rr = __builtin_sqrtf(hash1(seed));
+    float rr = sqrt_rn(hash1(seed));
     float rdx = K.lens_radius * (rr * ca);
     float rdy = K.lens_radius * (rr * sa);
     V3 off = mk(fma_(K.cam_v[0], rdy, K.cam_u[0] * rdx), fma_(K.cam_v[1], rdy, K.cam_u[1] * rdx),
@@ -614,14 +719,14 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // loop so that node steps and leaf steps do not serialise against each other.
       const uint32_t n_nodes = A.n_nodes;
       const bool fresh = scan_lane && !carried;
+      const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
+      const uint32_t a_guard = hit_root_guard(a);
 
       auto eval_slot = [&](uint32_t pos) {
         const float4 g = slot_at(pos);
         PT_TEST(g, half_b, c, disc)
         (void)c;
-        const float sqrtd = __builtin_sqrtf(disc);
-        float v = (-half_b - sqrtd) / a;             // :158
-        if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; // :159-160
+        const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161
         // order-free form of the shader's acceptance: smaller root wins, equal roots go to the
         // LATER sphere of the list (no hit yet loses to everything, so v == MAX_T is accepted as
         // in :159).  Sphere indices are only looked up for the rare exact tie.
@@ -809,6 +914,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // every ray tests them first, through scalar loads.
       const uint32_t n_cell_entries = A.n_tree_slots;
       const bool fresh = scan_lane && !carried;
+      const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
+      const uint32_t a_guard = hit_root_guard(a);
 
       // exact part of hit_sphere for the candidates of ONE group of four entries (4-bit mask),
       // all lanes in lockstep: max-over-lanes(popcount) ~ 1-2 evaluations per group
@@ -822,9 +929,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       MASK &= MASK - 1u;                                                                        \
       const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));             \
       const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));               \
-      const float sqrtd = __builtin_sqrtf(disc);                                                \
-      float v = (-half_b - sqrtd) / a;             /* :158 */                                   \
-      if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; /* :159-160 */                               \
+      const float v = hit_root(half_b, disc, a, ya, a_guard); /* :156-161 */                       \
       const uint32_t pos = (BASE) + k;                                                          \
       /* order-free acceptance: smaller root wins, equal roots go to the LATER sphere of the   \
          list; indices are only looked up for the rare exact tie (a sphere registered in two   \
@@ -1063,6 +1168,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 #undef PT_GROUP
 
     // PHASE 2: exact evaluation of the queued candidates, newest (largest index) first
+    const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
+    const uint32_t a_guard = hit_root_guard(a);
     while (pt_ballot(q_cnt != 0u) != 0ull) {
       if (q_cnt != 0u) {
         const uint32_t idx = q0 & 0xffffu;
@@ -1073,9 +1180,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         const float4 g = geom_at(idx);
         PT_TEST(g, half_b, c, disc) // bit-identical to the scan's values
         (void)c;
-        const float sqrtd = __builtin_sqrtf(disc);
-        float v = (-half_b - sqrtd) / a;               // :158
-        if (v < PT_MIN_T) v = (-half_b + sqrtd) / a;   // :159-160 (see the note above)
+        const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161 (see the note above)
         const bool in_range = !(v < PT_MIN_T) && (v < closest || (hit < 0 && v <= closest));
         if (in_range) {
           closest = v;
@@ -1151,7 +1256,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       bool finished = false; // this camera path is over
       if (hit < 0) {
         if (A.background_mode == 0) { // background(), :289-294
-          float inv = 1.0f / __builtin_sqrtf(a);
+          float inv = 1.0f / sqrt_rn(a);
           float uy = d.y * inv;
           float t = 0.5f * (uy + 1.0f);
           float omt = 1.0f - t;
@@ -1175,7 +1280,24 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         float radius = m1.z;
         // hit record, :166-171
         V3 p = mk(fma_(d.x, closest, o.x), fma_(d.y, closest, o.y), fma_(d.z, closest, o.z));
-        V3 on = mk((p.x - g.x) / radius, (p.y - g.y) / radius, (p.z - g.z) / radius);
+        // outward normal (p - centre) / radius, :168: three divisions by one denominator.  Fast form
+        // when |radius| is in [2^-20, 2^20) and every numerator has 2^-103 <= |n| < 2^76 (a zero
+        // numerator takes the plain operator: its quotient's sign of zero comes from v_div_fixup)
+        const float nx = p.x - g.x, ny = p.y - g.y, nz = p.z - g.z;
+        V3 on;
+#if PT_FAST_NORMAL
+        const float n_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
+        const float n_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
+        const uint32_t r_guard = div_den_ok(radius) ? f2u(0x1p76f) - f2u(0x1p-103f) : 0u;
+        const bool n_odd = f2u(n_lo) - f2u(0x1p-103f) >= r_guard || f2u(n_hi) - f2u(0x1p-103f) >= r_guard;
+        if (__builtin_expect(pt_ballot(n_odd) == 0ull, 1)) {
+          const float yr = rcp_newton(radius);
+          on = mk(div_core(nx, radius, yr), div_core(ny, radius, yr), div_core(nz, radius, yr));
+        } else // (rare)
+#endif
+        {
+          on = mk(nx / radius, ny / radius, nz / radius);
+        }
         bool front = dot3(d, on) < 0.0f; // :137
         V3 n = front ? on : mk(-on.x, -on.y, -on.z);
         V3 alb = mk(m0.x, m0.y, m0.z);
@@ -1202,11 +1324,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         } else if (mtype == 2) { // GLASS :250-282
           float ri = m1.x;
           float ratio = front ? (1.0f / ri) : ri;
-          float inv = 1.0f / __builtin_sqrtf(a);
+          float inv = 1.0f / sqrt_rn(a);
           V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
           float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
           float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
-          float sin_theta = __builtin_sqrtf(fma_(-cos_theta, cos_theta, 1.0f));
+          float sin_theta = sqrt_rn(fma_(-cos_theta, cos_theta, 1.0f));
           bool cannot_refract = ratio * sin_theta > 1.0f;
           float refl_amount = reflectance(cos_theta, ratio);
           float rnd = hash1(seed);
@@ -1219,7 +1341,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             if (k < 0.0f) {
               nd = mk(0.f, 0.f, 0.f);
             } else {
-              float t = fma_(ratio, dni, __builtin_sqrtf(k));
+              float t = fma_(ratio, dni, sqrt_rn(k));
               nd = mk(fma_(-t, n.x, ratio * ud.x), fma_(-t, n.y, ratio * ud.y),
                       fma_(-t, n.z, ratio * ud.z));
             }
@@ -1520,6 +1642,23 @@ extern "C" __global__ void pt_probe_kernel(int kind, const float* in, float* out
       float x = in[2 * (size_t)i], y = in[2 * (size_t)i + 1];
       float* o = out + 3 * (size_t)i;
       o[0] = x / y; o[1] = __builtin_sqrtf(__builtin_fabsf(x)); o[2] = fma_(x, y, x);
+      break;
+    }
+    case PT_PROBE_FAST_ARITH: { // the unscaled sqrt / division forms beside the plain operators
+      const float x = in[3 * (size_t)i], y = in[3 * (size_t)i + 1], z = in[3 * (size_t)i + 2];
+      float* o = out + 8 * (size_t)i;
+      o[0] = x / y;
+      o[1] = div_core(x, y, rcp_newton(y));
+      o[2] = __builtin_sqrtf(x);
+      o[3] = sqrt_core(x);
+      o[4] = sqrt_rn(x);
+      // hit_root(half_b = x, disc = y, a = z) and static/shader.frag:156-161 written out
+      o[5] = hit_root(x, y, z, rcp_newton(z), hit_root_guard(z));
+      const float sqrtd = __builtin_sqrtf(y);
+      float v = (-x - sqrtd) / z;
+      if (v < PT_MIN_T) v = (-x + sqrtd) / z;
+      o[6] = v;
+      o[7] = div_den_ok(y) ? 1.0f : 0.0f;
       break;
     }
     case PT_PROBE_BASE_HASH: {

@@ -19,7 +19,7 @@ from ray_tracer_webgl_amd.tracer import PathTracer, PtError, render_scene
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
-PROBE_HASH, PROBE_SINCOS, PROBE_CBRT, PROBE_UNIT_SPHERE, PROBE_DIVSQRT, PROBE_BASE_HASH = range(6)
+PROBE_HASH, PROBE_SINCOS, PROBE_CBRT, PROBE_UNIT_SPHERE, PROBE_DIVSQRT, PROBE_BASE_HASH, PROBE_FAST_ARITH = range(7)
 
 
 def bits(a):
@@ -114,6 +114,62 @@ def test_probe_ieee_div_sqrt_fma(pt):
     # double-rounding can differ from a true fma in rare halfway cases; allow those only
     mism = bits(out[:, 2]) != bits(ref_fma)
     assert mism.mean() < 1e-4
+
+
+def _log_uniform(rng, n, lo_exp, hi_exp, signed=True):
+    v = np.ldexp(rng.uniform(1.0, 2.0, n), rng.integers(lo_exp, hi_exp, n)).astype(np.float32)
+    return v * rng.choice([-1.0, 1.0], n).astype(np.float32) if signed else v
+
+
+def test_probe_unscaled_div_sqrt_match_the_operators(pt):
+    """pt_kernels.hip's div_core / sqrt_core (the compiler's correctly rounded expansions without
+    their range scaling) return the operators' bits on the operand ranges their call sites
+    guard; sqrt_rn and hit_root fall back outside them, so they match everywhere (hit_root up to
+    roots below MIN_T, which the caller only ever compares with MIN_T)."""
+    rng = np.random.default_rng(77)
+    n = 1 << 21
+    # 1. guarded ranges: |b| in [2^-20, 2^20], |n| in [2^-103, 2^76); x in [2^-96, 2^127]
+    num = _log_uniform(rng, n, -103, 76)
+    den = _log_uniform(rng, n, -20, 20)
+    den[: n // 4] = rng.uniform(0.25, 4.0, n // 4).astype(np.float32)  # typical |d|^2
+    num[: n // 8] = rng.normal(0, 3, n // 8).astype(np.float32)
+    num[np.abs(num) < 2.0 ** -103] = 1.0
+    x = _log_uniform(rng, n, -96, 127, signed=False)
+    x[: n // 4] = rng.uniform(0, 1, n // 4).astype(np.float32) ** 2  # typical discriminants
+    x[x < 2.0 ** -96] = 2.0 ** -96
+    out = pt.probe(PROBE_FAST_ARITH, np.stack([num, den, np.ones_like(num)], 1).ravel(), 8, n).reshape(-1, 8)
+    assert out[:, 7].all()
+    assert_bit_equal(out[:, 1], out[:, 0], "div_core vs /")
+    with np.errstate(all="ignore"):
+        assert_bit_equal(out[:, 0], (num / den).astype(np.float32), "/ vs numpy")
+    out = pt.probe(PROBE_FAST_ARITH, np.stack([x, np.ones_like(x), np.ones_like(x)], 1).ravel(), 8, n).reshape(-1, 8)
+    assert_bit_equal(out[:, 3], out[:, 2], "sqrt_core vs sqrt")
+    assert_bit_equal(out[:, 2], np.sqrt(x.astype(np.float64)).astype(np.float32), "sqrt vs numpy")
+    # 2. sqrt_rn: any operand (tiny, denormal, zero, negative, inf, NaN)
+    odd = np.concatenate([_log_uniform(rng, 200000, -149, 128), np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 2.0 ** -96, 2.0 ** -97], np.float32)])
+    out = pt.probe(PROBE_FAST_ARITH, np.stack([odd, np.ones_like(odd), np.ones_like(odd)], 1).ravel(), 8, len(odd)).reshape(-1, 8)
+    both_nan = np.isnan(out[:, 4]) & np.isnan(out[:, 2])
+    assert np.array_equal(bits(out[:, 4])[~both_nan], bits(out[:, 2])[~both_nan])
+    # 3. hit_root(half_b, disc, a) against the literal two-root formula, operands of every size
+    m = 1 << 20
+    hb = _log_uniform(rng, m, -140, 120)
+    disc = _log_uniform(rng, m, -140, 127, signed=False)
+    a = _log_uniform(rng, m, -30, 30, signed=False)
+    k = m // 2  # half of them shaped like real candidates: disc ~ hb^2 (self-intersections: far root ~ 0)
+    hb[:k] = rng.normal(0, 2, k).astype(np.float32)
+    disc[:k] = (hb[:k].astype(np.float64) ** 2 * (1.0 + rng.choice([0.0, 1e-7, -1e-7, 1e-3, 0.5], k))).astype(np.float32)
+    a[:k] = rng.uniform(0.5, 2.0, k).astype(np.float32)
+    extra = np.array([[1.0, 0.0, 1.0], [-1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [0.0, 0.0, 1.0], [1e30, 1e20, 1.0], [1.0, np.inf, 1.0],
+                      [1.0, np.nan, 1.0], [1.0, 1.0, 0.0], [1.0, 1.0, 1e-30], [1e-40, 1e-44, 1.0]], np.float32)
+    inp = np.concatenate([np.stack([hb, disc, a], 1), extra]).astype(np.float32)
+    out = pt.probe(PROBE_FAST_ARITH, inp.ravel(), 8, len(inp)).reshape(-1, 8)
+    fast, plain = out[:, 5], out[:, 6]
+    same = (bits(fast) == bits(plain)) | (np.isnan(fast) & np.isnan(plain))
+    with np.errstate(invalid="ignore"):
+        below = (fast < 0.001) & (plain < 0.001)
+    bad = ~(same | below)
+    assert not bad.any(), (int(bad.sum()), inp[bad][:5], fast[bad][:5], plain[bad][:5])
+    assert same.mean() > 0.9  # the fast form is what normally runs
 
 
 # -------------------------------------------------------------------------------- full frames
