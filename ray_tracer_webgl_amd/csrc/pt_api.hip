@@ -72,6 +72,7 @@ struct pt_ctx {
   float* d_bvh_nodes32 = nullptr;
   float* d_bvh_slots = nullptr;
   uint32_t* d_bvh_index = nullptr;
+  PtMatRec* d_bvh_mat = nullptr;   // per slot: the material of the slot's sphere
   size_t bvh_node_cap = 0, bvh_slot_cap = 0;
   uint32_t bvh_n_nodes = 0, bvh_n_slots = 0, bvh_n_tree_slots = 0, bvh_n_outliers = 0, bvh_depth = 0;
   float bvh_c0[3] = {0, 0, 0}, bvh_s0 = 0, bvh_kinv = 1;
@@ -80,6 +81,7 @@ struct pt_ctx {
   uint32_t* d_grid_cells = nullptr;
   float* d_grid_entries = nullptr;
   uint32_t* d_grid_index = nullptr;
+  PtMatRec* d_grid_mat = nullptr;
   size_t grid_cell_cap = 0, grid_entry_cap = 0;
   ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
   int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
@@ -300,10 +302,12 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_bvh_nodes32) (void)hipFree(c->d_bvh_nodes32);
   if (c->d_bvh_slots) (void)hipFree(c->d_bvh_slots);
   if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
+  if (c->d_bvh_mat) (void)hipFree(c->d_bvh_mat);
   if (c->d_wave_log) (void)hipFree(c->d_wave_log);
   if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
   if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
   if (c->d_grid_index) (void)hipFree(c->d_grid_index);
+  if (c->d_grid_mat) (void)hipFree(c->d_grid_mat);
   if (c->own_accum) (void)hipFree(c->own_accum);
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_resolve) (void)hipFree(c->d_resolve);
@@ -396,9 +400,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     if (bvh.slots.size() > c->bvh_slot_cap) {
       if (c->d_bvh_slots) PT_HIP(c, hipFree(c->d_bvh_slots));
       if (c->d_bvh_index) PT_HIP(c, hipFree(c->d_bvh_index));
-      c->d_bvh_slots = nullptr; c->d_bvh_index = nullptr; c->bvh_slot_cap = 0;
+      if (c->d_bvh_mat) PT_HIP(c, hipFree(c->d_bvh_mat));
+      c->d_bvh_slots = nullptr; c->d_bvh_index = nullptr; c->d_bvh_mat = nullptr; c->bvh_slot_cap = 0;
       PT_HIP(c, hipMalloc(&c->d_bvh_slots, bvh.slots.size() * sizeof(float)));
       PT_HIP(c, hipMalloc(&c->d_bvh_index, bvh.slot_index.size() * sizeof(uint32_t)));
+      PT_HIP(c, hipMalloc(&c->d_bvh_mat, bvh.slot_index.size() * sizeof(PtMatRec)));
       c->bvh_slot_cap = bvh.slots.size();
     }
     PT_HIP(c, hipMemcpy(c->d_bvh_nodes, bvh.nodes16.data(), bvh.nodes16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -406,6 +412,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     PT_HIP(c, hipMemcpy(c->d_bvh_slots, bvh.slots.data(), bvh.slots.size() * sizeof(float), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_bvh_index, bvh.slot_index.data(), bvh.slot_index.size() * sizeof(uint32_t),
                         hipMemcpyHostToDevice));
+    {
+      std::vector<PtMatRec> sm(bvh.slot_index.size());
+      for (size_t k = 0; k < sm.size(); k++) sm[k] = bvh.slot_index[k] < n ? mat[bvh.slot_index[k]] : PtMatRec{};
+      PT_HIP(c, hipMemcpy(c->d_bvh_mat, sm.data(), sm.size() * sizeof(PtMatRec), hipMemcpyHostToDevice));
+    }
     c->bvh_n_nodes = bvh.n_nodes; c->bvh_n_slots = bvh.n_slots; c->bvh_n_tree_slots = bvh.n_tree_slots;
     c->bvh_n_outliers = bvh.n_outliers; c->bvh_depth = bvh.depth;
     for (int k = 0; k < 3; k++) c->bvh_c0[k] = bvh.c0[k];
@@ -428,9 +439,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     if (n_ent_pad > c->grid_entry_cap) {
       if (c->d_grid_entries) PT_HIP(c, hipFree(c->d_grid_entries));
       if (c->d_grid_index) PT_HIP(c, hipFree(c->d_grid_index));
-      c->d_grid_entries = nullptr; c->d_grid_index = nullptr; c->grid_entry_cap = 0;
+      if (c->d_grid_mat) PT_HIP(c, hipFree(c->d_grid_mat));
+      c->d_grid_entries = nullptr; c->d_grid_index = nullptr; c->d_grid_mat = nullptr; c->grid_entry_cap = 0;
       PT_HIP(c, hipMalloc(&c->d_grid_entries, n_ent_pad * 16));
       PT_HIP(c, hipMalloc(&c->d_grid_index, n_ent_pad * sizeof(uint32_t)));
+      PT_HIP(c, hipMalloc(&c->d_grid_mat, n_ent_pad * sizeof(PtMatRec)));
       c->grid_entry_cap = n_ent_pad;
     }
     PT_HIP(c, hipMemset(c->d_grid_cells, 0, n_cells_pad * sizeof(uint32_t)));
@@ -439,6 +452,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     PT_HIP(c, hipMemcpy(c->d_grid_entries, grid.entries.data(), (size_t)grid.n_entries * 16, hipMemcpyHostToDevice));
     PT_HIP(c, hipMemset(c->d_grid_index, 0xff, n_ent_pad * sizeof(uint32_t)));
     PT_HIP(c, hipMemcpy(c->d_grid_index, grid.entry_index.data(), (size_t)grid.n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+      std::vector<PtMatRec> sm(n_ent_pad);
+      for (size_t k = 0; k < (size_t)grid.n_entries; k++) sm[k] = grid.entry_index[k] < n ? mat[grid.entry_index[k]] : PtMatRec{};
+      PT_HIP(c, hipMemcpy(c->d_grid_mat, sm.data(), sm.size() * sizeof(PtMatRec), hipMemcpyHostToDevice));
+    }
     grid.cells.clear(); grid.cells.shrink_to_fit();
     grid.entries.clear(); grid.entries.shrink_to_fit();
     grid.entry_index.clear(); grid.entry_index.shrink_to_fit();
@@ -683,6 +701,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       A.bvh_nodes32 = c->d_bvh_nodes32;
       A.bvh_slots = c->d_bvh_slots;
       A.bvh_slot_index = c->d_bvh_index;
+      A.slot_mat = c->d_bvh_mat;
       A.n_nodes = c->bvh_n_nodes;
       A.n_tree_slots = c->bvh_n_tree_slots;
       A.n_slots = c->bvh_n_slots;
@@ -707,6 +726,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
       const ptgrid::Grid& g = c->grid;
       A.bvh_slots = c->d_grid_entries;
       A.bvh_slot_index = c->d_grid_index;
+      A.slot_mat = c->d_grid_mat;
       A.grid_cells = c->d_grid_cells;
       A.n_cells = g.n[0] * g.n[1] * g.n[2];
       A.n_tree_slots = g.n_cell_entries;

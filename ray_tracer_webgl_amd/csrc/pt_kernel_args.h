@@ -61,6 +61,7 @@ struct PtKernelArgs {
   const float* bvh_slots;          // n_slots x {cx, cy, cz, r*r}: leaves / cell groups (4 slots each), then the
                                    // spheres tested for every ray (padded to 4)
   const uint32_t* bvh_slot_index;  // n_slots: original sphere index of a slot
+  const PtMatRec* slot_mat;        // n_slots: the slot's material record (a copy: shading needs no index look-up)
   uint32_t n_nodes, n_tree_slots, n_slots, n_outliers;
   float bvh_c0[3], bvh_s0;         // hierarchy: per-ray margin = 1.25e-3 (|o - c0|_1 + s0) + 1e-6; grid: D = |o - c0| + s0
   // uniform grid (PT_GEOM_GRID)

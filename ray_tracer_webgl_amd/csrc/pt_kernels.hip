@@ -899,7 +899,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       drain_to(0u);
       carried = cur < walk_end;
       if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(carried));
-      if (hit_pos != 0xffffffffu) hit = (int)A.bvh_slot_index[hit_pos];
+      if (hit_pos != 0xffffffffu) hit = 0; // a hit; shading reads the slot's own copies (index not needed)
     } else if constexpr (GRID) {
       // PHASE 1 (uniform grid, pt_grid.hpp).  The ORDER in which spheres are looked at is free and
       // spheres that cannot pass need not be looked at (note at PHASE 1 above).  A sphere can be
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 #undef PT_PASSES
       carried = gactive || (pend >> 24) != 0u;
       if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(carried));
-      if (hit_pos != 0xffffffffu) hit = (int)A.bvh_slot_index[hit_pos];
+      if (hit_pos != 0xffffffffu) hit = 0; // a hit; shading reads the slot's own copies (index not needed)
     } else {
     uint32_t q_cnt = 0, q0 = 0, q1 = 0, q2 = 0; // candidate queue, newest in the low half of q0
     auto note_candidate = [&](uint32_t idx, float half_b, float c) {
@@ -1274,6 +1274,9 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
           g = geom_at((uint32_t)hit);
         }
         const float4* mp = reinterpret_cast<const float4*>(A.mat + hit);
+        if constexpr (TREE) { // one load instead of index -> material (two dependent memory round trips)
+          if (hit_pos != 0xffffffffu) mp = reinterpret_cast<const float4*>(A.slot_mat + hit_pos);
+        }
         float4 m0 = mp[0]; // albedo.xyz, fuzz
         float4 m1 = mp[1]; // refraction_index, type, radius, uuid
         int mtype = __float_as_int(m1.y);
