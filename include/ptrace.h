@@ -76,7 +76,9 @@ enum {
   PT_OPT_COUNT_WORK = 2,  /* 1: the walk kernels' measuring twins fill PtStats.work (slower; never time them) */
   PT_OPT_CARRY_LANES = 3, /* walk kernels: move on to shading when fewer lanes than this (and less than half
                              of the wave) are still walking; the stragglers continue in the next wave step.
-                             Scheduling only — images do not depend on it.  0 = lockstep.  Default 12. */
+                             The grid walk raises the threshold by 4 per iteration a step's walk has already
+                             run (scenes of long walks).  Scheduling only — images do not depend on it.
+                             0 = lockstep.  Default 12. */
   PT_OPT_REFILL_MIN = 4,  /* lanes of a busy wave that wait for a new work item before the (wave-wide) item
                              decode runs for them.  Scheduling only.  1 = refill at once.  Default 4. */
 };

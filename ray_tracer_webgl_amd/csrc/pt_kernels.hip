@@ -1106,7 +1106,11 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         const unsigned long long m_on = pt_ballot(gactive || (pend >> 24) != 0u);
         if (m_on == 0ull) break;
         const uint32_t n_on = (uint32_t)__popcll(m_on);
-        if (walk_iters >= 2u && n_on < A.carry_lanes && 2u * n_on < (uint32_t)n_live) break; // carry the stragglers
+        // carry the stragglers: the longer this step's walk has run, the more lanes may be left behind
+        // (a long walk means a scene of long walks, where waiting for the last quarter of the lanes costs
+        // more than shading at three quarters; short walks never get past the base threshold)
+        if (walk_iters >= 2u && A.carry_lanes != 0u && n_on < A.carry_lanes + 4u * (walk_iters - 2u) &&
+            2u * n_on < (uint32_t)n_live) break;
       }
 #undef PT_EXACT_GROUP
 #undef PT_PASSES
