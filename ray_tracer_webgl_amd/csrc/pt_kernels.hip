@@ -208,21 +208,29 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 // and is never looked at: a root below MIN_T is only compared with MIN_T — a near root is
 // replaced by the far root, a far root rejected).
 __device__ __forceinline__ float hit_root(float half_b, float disc, float a, float ya, uint32_t guard) {
-  float v;
 #if PT_FAST_EXACT
+  // straight-line fast form (both roots: the far one is needed by some lane in most evaluations, and
+  // five multiply-adds cost less than the divergent region around them) ...
+  const float sqrtd = sqrt_core(disc);
+  const float v_near = div_core(-half_b - sqrtd, a, ya);
+  const float v_far = div_core(-half_b + sqrtd, a, ya);
+  float v = v_near < PT_MIN_T ? v_far : v_near;
+  // ... and, if any lane's operands are outside the guarded range, the plain operators for those lanes
   const bool odd = f2u(disc) - f2u(0x1p-96f) >= guard;
-  if (__builtin_expect(pt_ballot(odd) == 0ull, 1)) {
-    const float sqrtd = sqrt_core(disc);
-    v = div_core(-half_b - sqrtd, a, ya);
-    if (v < PT_MIN_T) v = div_core(-half_b + sqrtd, a, ya);
-  } else // (rare) the plain operators for the whole wave
-#endif
-  {
-    const float sqrtd = __builtin_sqrtf(disc);
-    v = (-half_b - sqrtd) / a;             // :158
-    if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; // :159-160
+  if (__builtin_expect(pt_ballot(odd) != 0ull, 0)) { // (rare)
+    if (odd) {
+      const float s = __builtin_sqrtf(disc);
+      v = (-half_b - s) / a;             // :158
+      if (v < PT_MIN_T) v = (-half_b + s) / a; // :159-160
+    }
   }
   return v;
+#else
+  const float sqrtd = __builtin_sqrtf(disc);
+  float v = (-half_b - sqrtd) / a;             // :158
+  if (v < PT_MIN_T) v = (-half_b + sqrtd) / a; // :159-160
+  return v;
+#endif
 }
 
 // static/shader.frag:114-121
@@ -1297,14 +1305,14 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         const float n_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
         const uint32_t r_guard = div_den_ok(radius) ? f2u(0x1p76f) - f2u(0x1p-103f) : 0u;
         const bool n_odd = f2u(n_lo) - f2u(0x1p-103f) >= r_guard || f2u(n_hi) - f2u(0x1p-103f) >= r_guard;
-        if (__builtin_expect(pt_ballot(n_odd) == 0ull, 1)) {
-          const float yr = rcp_newton(radius);
-          on = mk(div_core(nx, radius, yr), div_core(ny, radius, yr), div_core(nz, radius, yr));
-        } else // (rare)
-#endif
-        {
-          on = mk(nx / radius, ny / radius, nz / radius);
+        const float yr = rcp_newton(radius);
+        on = mk(div_core(nx, radius, yr), div_core(ny, radius, yr), div_core(nz, radius, yr));
+        if (__builtin_expect(pt_ballot(n_odd) != 0ull, 0)) { // (rare)
+          if (n_odd) on = mk(nx / radius, ny / radius, nz / radius);
         }
+#else
+        on = mk(nx / radius, ny / radius, nz / radius);
+#endif
         bool front = dot3(d, on) < 0.0f; // :137
         V3 n = front ? on : mk(-on.x, -on.y, -on.z);
         V3 alb = mk(m0.x, m0.y, m0.z);

@@ -159,6 +159,8 @@ def test_probe_unscaled_div_sqrt_match_the_operators(pt):
     hb[:k] = rng.normal(0, 2, k).astype(np.float32)
     disc[:k] = (hb[:k].astype(np.float64) ** 2 * (1.0 + rng.choice([0.0, 1e-7, -1e-7, 1e-3, 0.5], k))).astype(np.float32)
     a[:k] = rng.uniform(0.5, 2.0, k).astype(np.float32)
+    # hit_root's precondition: disc = fma(-a, c, half_b * half_b), so a finite disc means the square did not overflow
+    disc[np.abs(hb) >= 2.0 ** 63] = np.inf
     extra = np.array([[1.0, 0.0, 1.0], [-1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [0.0, 0.0, 1.0], [1e30, 1e20, 1.0], [1.0, np.inf, 1.0],
                       [1.0, np.nan, 1.0], [1.0, 1.0, 0.0], [1.0, 1.0, 1e-30], [1e-40, 1e-44, 1.0]], np.float32)
     inp = np.concatenate([np.stack([hb, disc, a], 1), extra]).astype(np.float32)
