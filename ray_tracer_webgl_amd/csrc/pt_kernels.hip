@@ -450,11 +450,20 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
 #define PT_PHASE(k) do { if constexpr (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_t[k] += now_ - ph_mark; ph_mark = now_; } } while (0)
 
   // start the next camera path of this lane's item: static/shader.frag:365-370 + :342-351
+  // the pixel jitter is divided by the image size (:367-368): uniform denominators, numerators that
+  // are 0 or >= 2^-31 and < 1, so div_core applies whenever width and height are in [2^-20, 2^20)
+  // (a +0 numerator gives +0 either way: positive operands)
+  const bool wh_ok = div_den_ok(K.fw) && div_den_ok(K.fh); // wave-uniform
+  const float y_fw = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(rcp_newton(K.fw)))); // uniform: kept in SGPRs
+  const float y_fh = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(rcp_newton(K.fh))));
   auto start_sample = [&]() {
     float r0, r1;
     hash2(seed, r0, r1);
-    float s = st_s + r0 / K.fw;
-    float t = st_t + r1 / K.fh;
+    float jx, jy;
+    if (wh_ok) { jx = div_core(r0, K.fw, y_fw); jy = div_core(r1, K.fh, y_fh); }
+    else { jx = r0 / K.fw; jy = r1 / K.fh; }
+    float s = st_s + jx;
+    float t = st_t + jy;
     float ua = hash1(seed); // random_in_unit_circle :123-129, consumed even if lens_radius == 0
     float sa, ca;
     sincos2pi(ua, sa, ca);
@@ -540,8 +549,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
             y = (b * K.band_count + K.band_index) * K.band_rows + r;
           }
           // static/shader.vert:8 + rasteriser: v_position at the pixel centre
-          float vx = (float)(2u * px + 1u) / K.fw - 1.0f;
-          float vy = (float)(2u * y + 1u) / K.fh - 1.0f;
+          const float fx2 = (float)(2u * px + 1u), fy2 = (float)(2u * y + 1u); // odd integers >= 1
+          float vx, vy;
+          if (wh_ok) { vx = div_core(fx2, K.fw, y_fw) - 1.0f; vy = div_core(fy2, K.fh, y_fh) - 1.0f; }
+          else { vx = fx2 / K.fw - 1.0f; vy = fy2 / K.fh - 1.0f; }
           float u_time = K.time0 + (float)(K.first_pass + pass) * K.time_step;
           // init_global_seed, static/shader.frag:354-357
           seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
