@@ -106,5 +106,5 @@ enum {
   PT_PROBE_UNIT_SPHERE = 3,// in: seed                 out: x,y,z,seed'
   PT_PROBE_DIVSQRT = 4,    // in: a,b                  out: a/b, sqrt(|a|), fma(a,b,a)
   PT_PROBE_BASE_HASH = 5,  // in: bits x, bits y       out: hash (as float bits)
-  PT_PROBE_FAST_ARITH = 6, // in: x,y,z                out: x/y, div_core, sqrt(x), sqrt_core, sqrt_rn, hit_root(x,y,z), plain roots, div_den_ok(y)
+  PT_PROBE_FAST_ARITH = 6, // in: x,y,z                out: x/y, div_core, sqrt(x), sqrt_core, sqrt_rn, hit_root(x,y,z), plain roots, div_den_ok(y), inv_sqrt_rn(x), 1/sqrt(x) (10 floats)
 };

@@ -195,6 +195,25 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 #endif
 }
 
+// 1.0f / sqrtf(x), both roundings as written (normalize(), background()): for x in [2^-40, 2^40) the
+// square root s is in [2^-20, 2^20) and the numerator is 1, so sqrt_core and div_core apply (with
+// n = 1 the first product of div_core is the reciprocal itself)
+__device__ __forceinline__ float inv_sqrt_rn(float x) {
+#if PT_FAST_SQRT
+  const float s = sqrt_core(x);
+  const float y = rcp_newton(s);
+  const float q1 = fma_(fma_(-s, y, 1.0f), y, y);
+  float r = fma_(fma_(-s, q1, 1.0f), y, q1);
+  const bool odd = !in_range_bits(x, 0x1p-40f, 0x1p40f);
+  if (__builtin_expect(pt_ballot(odd) != 0ull, 0)) { // (rare)
+    if (odd) r = 1.0f / __builtin_sqrtf(x);
+  }
+  return r;
+#else
+  return 1.0f / __builtin_sqrtf(x);
+#endif
+}
+
 // The exact part of hit_sphere, static/shader.frag:156-161, for a candidate with discriminant
 // disc = fma(-a, c, half_b * half_b) >= 0 (or NaN): the root `v` the shader would test first,
 // replaced by the far root when the near one is below MIN_T.  ya = rcp_newton(a) and
@@ -246,7 +265,7 @@ __device__ __forceinline__ V3 random_in_unit_sphere(float& seed) {
 }
 
 __device__ __forceinline__ V3 normalize3(V3 a) {
-  float inv = 1.0f / sqrt_rn(dot3(a, a));
+  float inv = inv_sqrt_rn(dot3(a, a));
   return mk(a.x * inv, a.y * inv, a.z * inv);
 }
 
@@ -1279,7 +1298,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       bool finished = false; // this camera path is over
       if (hit < 0) {
         if (A.background_mode == 0) { // background(), :289-294
-          float inv = 1.0f / sqrt_rn(a);
+          float inv = inv_sqrt_rn(a);
           float uy = d.y * inv;
           float t = 0.5f * (uy + 1.0f);
           float omt = 1.0f - t;
@@ -1350,7 +1369,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
         } else if (mtype == 2) { // GLASS :250-282
           float ri = m1.x;
           float ratio = front ? (1.0f / ri) : ri;
-          float inv = 1.0f / sqrt_rn(a);
+          float inv = inv_sqrt_rn(a);
           V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
           float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
           float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
@@ -1672,7 +1691,7 @@ extern "C" __global__ void pt_probe_kernel(int kind, const float* in, float* out
     }
     case PT_PROBE_FAST_ARITH: { // the unscaled sqrt / division forms beside the plain operators
       const float x = in[3 * (size_t)i], y = in[3 * (size_t)i + 1], z = in[3 * (size_t)i + 2];
-      float* o = out + 8 * (size_t)i;
+      float* o = out + 10 * (size_t)i;
       o[0] = x / y;
       o[1] = div_core(x, y, rcp_newton(y));
       o[2] = __builtin_sqrtf(x);
@@ -1685,6 +1704,8 @@ extern "C" __global__ void pt_probe_kernel(int kind, const float* in, float* out
       if (v < PT_MIN_T) v = (-x + sqrtd) / z;
       o[6] = v;
       o[7] = div_den_ok(y) ? 1.0f : 0.0f;
+      o[8] = inv_sqrt_rn(x);
+      o[9] = 1.0f / __builtin_sqrtf(x);
       break;
     }
     case PT_PROBE_BASE_HASH: {

@@ -137,19 +137,22 @@ def test_probe_unscaled_div_sqrt_match_the_operators(pt):
     x = _log_uniform(rng, n, -96, 127, signed=False)
     x[: n // 4] = rng.uniform(0, 1, n // 4).astype(np.float32) ** 2  # typical discriminants
     x[x < 2.0 ** -96] = 2.0 ** -96
-    out = pt.probe(PROBE_FAST_ARITH, np.stack([num, den, np.ones_like(num)], 1).ravel(), 8, n).reshape(-1, 8)
+    out = pt.probe(PROBE_FAST_ARITH, np.stack([num, den, np.ones_like(num)], 1).ravel(), 10, n).reshape(-1, 10)
     assert out[:, 7].all()
     assert_bit_equal(out[:, 1], out[:, 0], "div_core vs /")
     with np.errstate(all="ignore"):
         assert_bit_equal(out[:, 0], (num / den).astype(np.float32), "/ vs numpy")
-    out = pt.probe(PROBE_FAST_ARITH, np.stack([x, np.ones_like(x), np.ones_like(x)], 1).ravel(), 8, n).reshape(-1, 8)
+    out = pt.probe(PROBE_FAST_ARITH, np.stack([x, np.ones_like(x), np.ones_like(x)], 1).ravel(), 10, n).reshape(-1, 10)
     assert_bit_equal(out[:, 3], out[:, 2], "sqrt_core vs sqrt")
+    assert_bit_equal(out[:, 8], out[:, 9], "inv_sqrt_rn vs 1 / sqrt")
     assert_bit_equal(out[:, 2], np.sqrt(x.astype(np.float64)).astype(np.float32), "sqrt vs numpy")
     # 2. sqrt_rn: any operand (tiny, denormal, zero, negative, inf, NaN)
     odd = np.concatenate([_log_uniform(rng, 200000, -149, 128), np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 2.0 ** -96, 2.0 ** -97], np.float32)])
-    out = pt.probe(PROBE_FAST_ARITH, np.stack([odd, np.ones_like(odd), np.ones_like(odd)], 1).ravel(), 8, len(odd)).reshape(-1, 8)
+    out = pt.probe(PROBE_FAST_ARITH, np.stack([odd, np.ones_like(odd), np.ones_like(odd)], 1).ravel(), 10, len(odd)).reshape(-1, 10)
     both_nan = np.isnan(out[:, 4]) & np.isnan(out[:, 2])
     assert np.array_equal(bits(out[:, 4])[~both_nan], bits(out[:, 2])[~both_nan])
+    both_nan = np.isnan(out[:, 8]) & np.isnan(out[:, 9])
+    assert np.array_equal(bits(out[:, 8])[~both_nan], bits(out[:, 9])[~both_nan])  # inv_sqrt_rn, any operand
     # 3. hit_root(half_b, disc, a) against the literal two-root formula, operands of every size
     m = 1 << 20
     hb = _log_uniform(rng, m, -140, 120)
@@ -164,7 +167,7 @@ def test_probe_unscaled_div_sqrt_match_the_operators(pt):
     extra = np.array([[1.0, 0.0, 1.0], [-1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [0.0, 0.0, 1.0], [1e30, 1e20, 1.0], [1.0, np.inf, 1.0],
                       [1.0, np.nan, 1.0], [1.0, 1.0, 0.0], [1.0, 1.0, 1e-30], [1e-40, 1e-44, 1.0]], np.float32)
     inp = np.concatenate([np.stack([hb, disc, a], 1), extra]).astype(np.float32)
-    out = pt.probe(PROBE_FAST_ARITH, inp.ravel(), 8, len(inp)).reshape(-1, 8)
+    out = pt.probe(PROBE_FAST_ARITH, inp.ravel(), 10, len(inp)).reshape(-1, 10)
     fast, plain = out[:, 5], out[:, 6]
     same = (bits(fast) == bits(plain)) | (np.isnan(fast) & np.isnan(plain))
     with np.errstate(invalid="ignore"):
