@@ -168,3 +168,29 @@ def test_config2_full_resolution_whole_frame_vs_oracle(ora):
     assert np.array_equal(g, r), "%d of %d values differ" % ((g != r).sum(), g.size)
     assert t.stats().segments == seg
     t.close()
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py's N > 1 path on hardware, as far as a one-GPU box allows: two self-started ranks
+    (gloo collectives, both on cuda:0) render their row bands through libptrace; the line must
+    carry both ranks, the weak-scaling step (N x the passes per step) and the fixed-frame leg,
+    and rank 0's gathered frame must have been assembled (bench.py asserts its shape)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                        "--width", "480", "--height", "270", "--steps", "2", "--warmup", "1", "--steps-per-launch", "2",
+                        "--no-cpu-baseline", "--no-list-walk", "--no-work-count"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["scaling"] == "weak"
+    assert len(d["per_rank_render_kernel_ms"]) == 2 and min(d["per_rank_render_kernel_ms"]) > 0
+    assert d["config"]["passes_per_launch"] == 2 * 4 * 2  # steps per launch x passes per step x ranks
+    ff = d["fixed_frame"]
+    assert ff and ff["spp"] == 1024 and ff["scaling"] == "strong" and ff["sec"] > 0 and d["sec_to_converged_frame"] == ff["sec"]
+    assert d["value"] > 0 and d["segments"] > 0
