@@ -1492,7 +1492,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem(cons
 extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid(const PtKernelArgs A) {
   pt_trace_body<false, false, 4>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_cells(const PtKernelArgs A) {
   pt_trace_body<false, false, 5>(A);
 }
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem(const PtKernelArgs A) {
