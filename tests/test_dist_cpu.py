@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 (and 3) `gloo` process groups exercise the row-band
+"""The N>1 path on CPU: world_size-2 (and 3, and 8 with bench.py's 4-row bands) `gloo` process groups exercise the row-band
 partition and the all_gather/de-interleave of ray_tracer_webgl_amd/dist.py.  The per-rank render
 is injected (the oracle stands in for the HIP path here — tests may do that, the product never
 does), so what is under test is exactly the multi-rank logic bench.py runs over RCCL."""
@@ -41,6 +41,8 @@ def _worker(rank, world, port, band_rows, width, height, out_dir):
         local, seg, _ = ptdist.render_band(sc, rank, world, band_rows, render_fn=render_fn)
         assert local.shape[0] == abi.local_rows(height, band_rows, rank, world)
         full = ptdist.gather_rows(local, height, band_rows, rank, world)
+        again = ptdist.gather_rows(local, height, band_rows, rank, world)  # cached buffers and permutation
+        assert torch.equal(full, again) and full.data_ptr() != again.data_ptr()
         segs = torch.tensor([seg], dtype=torch.int64)
         dist.all_reduce(segs)
         np.save(os.path.join(out_dir, "full_%d.npy" % rank), full.numpy())
@@ -51,7 +53,7 @@ def _worker(rank, world, port, band_rows, width, height, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,band_rows,width,height", [(2, 8, 48, 37), (3, 4, 40, 30), (2, 8, 32, 5)])
+@pytest.mark.parametrize("world,band_rows,width,height", [(2, 8, 48, 37), (3, 4, 40, 30), (2, 8, 32, 5), (8, 4, 24, 70)])
 def test_row_band_render_and_gather_gloo(tmp_path, world, band_rows, width, height, ora):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, band_rows, width, height, str(tmp_path)), nprocs=world, join=True)
