@@ -785,7 +785,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 #ifdef PT_DEV_KNOBS // A/B builds only (tools/ab_*.sh); the product reads no environment
     if (const char* e = getenv("PT_BVH_BLOCK")) {
       uint32_t b = (uint32_t)atoi(e);
-      if (b == 256u || b == 512u || b == 1024u) bvh_block = b;
+      if (b >= 64u && b <= 1024u && b % 64u == 0u) bvh_block = b;
     }
     if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
 #endif

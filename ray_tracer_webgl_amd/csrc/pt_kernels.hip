@@ -523,7 +523,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       if (pool_next == pool_end) { // wave-uniform
         unsigned long long base = 0;
         if (lane == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
-        base = __shfl(base, 0);
+        // wave-uniform, and known to the compiler as such (readfirstlane): the pool bookkeeping derived
+        // from it then lives in SGPRs instead of occupying VGPRs for the kernel's lifetime
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
         if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
           if constexpr (COUNT) { if (t_wave_dry == 0) t_wave_dry = __builtin_amdgcn_s_memrealtime(); }
           if (need) exhausted = true;
