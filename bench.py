@@ -1,36 +1,45 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+"""bench.py — BASELINE.json's metric on BASELINE.json's configs.
 
-  metric   Mray/s (ray segments = hit_world invocations per second) at 1920x1080
-  workload config 2: Shirley cover scene (484 spheres), 1920x1080, 50 bounces, 1024 spp
-  step     one pass of the hot path over one batch = 64 samples for every pixel, rendered as
-           `--passes-per-step` (4) seeds of `--spp-per-pass` (16) samples each (u_time = (4 * step + j) x 0.3618:
-           the reference also accumulates many low-spp frames with distinct u_time, README.md:6);
-           the default 16 steps are exactly the config's 1024 spp "converged frame".  Steps are
-           enqueued `--steps-per-launch` at a time through pt_render_passes (one persistent kernel
-           launch works through all their (pixel, pass) items from one queue).
+  metric   Mray/s (ray segments = hit_world invocations per second)
+  workload --config 2 (default; the config the metric is quoted on): Shirley cover scene (484 spheres),
+           1920x1080, 50 bounces, 1024 spp;  --config 3: the same scene at 3840x2160, 4096 spp (BASELINE's
+           8-GPU case; fits one GPU too);  --config default: the reference's own operating point, see
+           frame_loop_bench() below (State::default, 1280x702, 1 spp per frame, depth 8, temporal blend).
+  step     one pass of the hot path over one batch = 64 samples for every pixel of the frame, rendered
+           as `--passes-per-step` (4) seeds of `--spp-per-pass` (16) samples each (u_time = (4 * step + j)
+           x 0.3618: the reference also accumulates many low-spp frames with distinct u_time,
+           README.md:6).  The default step count is exactly the config's converged frame (16 steps =
+           1024 spp for config 2, 64 steps = 4096 spp for config 3).  Steps are enqueued
+           `--steps-per-launch` at a time through pt_render_passes (one persistent kernel launch works
+           through all their (pixel, pass) items from one queue).
   N > 1    the image's rows are dealt to the ranks in interleaved 4-row bands (the path shards by
            pixel: no collective while rendering), ONE all_gather of the radiance buffers (RCCL over
-           xGMI) at the end of the timed region.  Default `--scaling weak`: per-GPU work is fixed —
-           a rank renders 1/N of the rows for N x 4 passes per step, so a step is N x 64 spp of the
-           whole frame (the same pass seeds a single GPU would use for that many passes; the
-           gathered image is bit-identical to the single-GPU one).  `--scaling strong` keeps the
-           frame fixed (4 passes per step whatever N).  Either way the line carries `fixed_frame`:
-           the config's own 1024-spp frame split over the N ranks, timed after the main region
-           with the same barriers (= the strong-scaling point; `sec_to_converged_frame` is that).
+           xGMI) at the end of the timed region.  Default `--scaling strong`: the SAME frame for every
+           N (north_star: the 1024-spp cover-scene frame "at 1/2/4/8 GPUs"): `value`, `ms_per_step`
+           and `sec_to_converged_frame` are on BASELINE's workload whatever N is, and rank 0 checks
+           the SHA-256 of the gathered frame against the committed single-GPU digest
+           (`gather_matches_single_gpu`) — the RCCL parity check.  The weak-scaling point (per-GPU
+           work fixed: 1/N of the rows x N x as many passes) is timed after the main region and
+           reported beside it as `weak_series`; `--scaling weak` makes it the main region instead.
            `python bench.py --gpus N` from a bare shell starts its N ranks itself (the parent never
            touches the GPU); under torch.distributed.run it uses the ranks it is given.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the path-tracing kernel against the FP32
 vector peak (the path has no dense contraction and ~1e5 FLOP per HBM byte):
 `frac` is EXECUTED lane-level fp32 work (from the kernel's own tallies, measuring twin run after
-the timed region) over the peak, always <= 1; what the reference's linear loop would have done for
-the same rays is `algorithmic_speedup_vs_list_walk`, and the linear walk itself is timed beside
-it (`list_walk`).  Everything is normalised PER PASS so any --steps gives the same ratios.
-`cpu_baseline` is the CPU oracle (rebuilt -O3 -march=native on this host) timed on this host's
-cores over a bounded sample of the same workload.
+the timed region) over the peak, always <= 1; beside this MODEL figure the line carries the
+counter-derived ones of the committed PMC profile of the same kernel and launch shape
+(`counters`: valu_issue_frac, lane_utilisation, fp32_flop_frac — labelled PRIOR, they are not
+this run's).  What the reference's linear loop would have done for the same rays is
+`algorithmic_speedup_vs_list_walk`, and the linear walk itself is timed beside it (`list_walk`).
+Everything is normalised PER PASS so any --steps gives the same ratios.  `cpu_baseline` is the CPU
+oracle (rebuilt -O3 -march=native on this host) timed on this host's cores over a bounded sample
+of the same workload.  `first_frame_ms` is what the steady-state figure hides: scene upload +
+structure builds + path autotune + one cold converged frame.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -51,7 +60,16 @@ FLOP_PER_CELL_STEP = 10        # grid: min3, two compares, three adds, bookkeepi
 FLOP_PER_LEAF_ROUND = 4 * FLOP_PER_SPHERE_TEST
 FLOP_PER_EXACT = 10            # sqrt, two divisions, sums, compares
 FLOP_PER_SEGMENT_SHADE = 150   # scatter + RNG + camera share
-CONVERGED_SPP = 1024           # BASELINE config 2
+
+# BASELINE.json configs bench.py can time: frame size, converged sample count, committed digest key
+# (tests/golden/full_frame_digests.json: the single-GPU frame rendered as passes of 16 spp with
+# decorrelated pass times, exactly what the default flags of this script render)
+BENCH_CONFIGS = {
+    "2": {"name": "config2", "width": 1920, "height": 1080, "spp": 1024,
+          "digest": "config2_1920x1080_64x16spp_decorrelated"},
+    "3": {"name": "config3", "width": 3840, "height": 2160, "spp": 4096,
+          "digest": "config3_3840x2160_256x16spp_decorrelated"},
+}
 
 
 def usable_cores():
@@ -119,26 +137,56 @@ def spawn_selftest(mode):
     return 0
 
 
+def frame_digest(full):
+    """SHA-256 of the (height, width, 4) fp32 radiance frame, as tests/golden/make_full_digests.py
+    computes it."""
+    import numpy as np
+
+    a = full.detach().cpu().numpy() if hasattr(full, "detach") else full
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()
+
+
+def load_digests():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "full_frame_digests.json")))
+    except Exception:
+        return {}
+
+
+def plan_steps(converged_spp, spp_per_pass, passes_per_step, steps):
+    """(steps, spp per step): the default step count is the config's converged frame."""
+    spp_step = spp_per_pass * passes_per_step
+    if steps is None:
+        steps = max(1, converged_spp // spp_step)
+    return steps, spp_step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--config", default="2", choices=["2", "3", "default"],
+                    help="BASELINE config: 2 = cover scene 1920x1080 1024 spp (the metric's config), 3 = the same at "
+                         "3840x2160 4096 spp, default = the reference's own 1-spp frame loop on State::default")
+    ap.add_argument("--steps", type=int, default=None, help="default: the config's converged frame (16 / 64)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--steps-per-launch", type=int, default=16)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp-per-pass", type=int, default=16)
     ap.add_argument("--passes-per-step", type=int, default=4)
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--band-rows", type=int, default=4,
                     help="N > 1: rows per interleaved band (4: rank shares of the work within 1 %% of each other at N = 8)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = passes per step grow with N (fixed work per GPU); strong = the same frame for every N")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the same frame for every N (BASELINE's workload); weak = passes per step grow with N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-list-walk", action="store_true",
                     help="skip the extra (untimed-region) launch that measures the reference's linear list walk")
     ap.add_argument("--no-work-count", action="store_true", help="skip the measuring-twin launch (roofline.frac = null)")
+    ap.add_argument("--no-first-frame", action="store_true", help="skip the cold first-frame measurement")
+    ap.add_argument("--no-weak-series", action="store_true", help="N > 1: skip the weak-scaling point after the main region")
     ap.add_argument("--cpu-strip", type=int, default=960, help="width of the CPU baseline's column strip")
+    ap.add_argument("--frames", type=int, default=400, help="--config default: frames per timed replay series")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -152,12 +200,19 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))  # before anything touches the GPU
     if args.spawn_selftest:
         raise SystemExit(spawn_selftest(args.spawn_selftest))
+    if args.config == "default":
+        raise SystemExit(frame_loop_bench(args))
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
 
     from ray_tracer_webgl_amd import abi, dist as ptdist, scenes
     from ray_tracer_webgl_amd.tracer import PathTracer
+
+    cfg = BENCH_CONFIGS[args.config]
+    width = args.width or cfg["width"]
+    height = args.height or cfg["height"]
+    converged_spp = cfg["spp"]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,7 +236,9 @@ def main():
         ranks_seen = dist.get_world_size()
 
     pps_frame = max(1, args.passes_per_step)  # passes per step of the single-GPU workload
-    pps = pps_frame * (world if args.scaling == "weak" else 1)  # passes per step on this rank's rows
+    weak = args.scaling == "weak" and world > 1
+    pps = pps_frame * (world if weak else 1)  # passes per step on this rank's rows
+    steps, spp_step_frame = plan_steps(converged_spp, args.spp_per_pass, pps_frame, args.steps)
     spp_step = args.spp_per_pass * pps
 
     def gather(t):
@@ -189,27 +246,39 @@ def main():
             return ptdist.gather_rows(t.cpu(), p.height, band_rows, rank, world)
         return ptdist.gather_rows(t, p.height, band_rows, rank, world)
 
-    sc = scenes.config2(args.width, args.height, args.spp_per_pass, args.steps * pps, args.max_depth)
+    make = scenes.config3 if args.config == "3" else scenes.config2
+    sc = make(width, height, args.spp_per_pass, steps * pps, args.max_depth)
     p = sc.params.copy()
     band_rows = args.band_rows
     p.band_rows, p.band_index, p.band_count = ptdist.band_of(rank, world, band_rows)
     p.time_step = abi.PT_TIME_STEP_DECORRELATED  # independent passes (include/ptrace.h)
 
-    pt = PathTracer(p.width, p.height, device=local_rank, use_torch=True)
-    pt.set_spheres(sc.spheres)
-    pt.set_params(p)
-    spl = max(1, min(args.steps_per_launch, max(args.steps, 1)))
+    spl = max(1, min(args.steps_per_launch, max(steps, 1)))
     ppl = spl * pps  # passes per launch
-    pt.reserve_passes(ppl)
-    # set-up, like reserving the workspace: settle how PHASE 1 looks at the sphere list (list
-    # walks, hierarchy, grid: bit-identical images) by measuring each once on this scene
-    pt.tune(ppl)
+    # the weak-scaling point after a strong main region needs world x the passes per launch
+    # (over 1/world of the rows: the same slab memory as the single-GPU launch)
+    want_weak_series = world > 1 and not weak and not args.no_weak_series
+    reserve = ppl * (world if want_weak_series else 1)
 
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # ---- set-up + the cold first frame (what the steady-state figures below do not show) ----------
+    sync_all()
+    tf0 = time.perf_counter()
+    pt = PathTracer(p.width, p.height, device=local_rank, use_torch=True)
+    pt.set_spheres(sc.spheres)  # upload + hierarchy and grid builds
+    pt.set_params(p)
+    pt.reserve_passes(reserve)
+    tf1 = time.perf_counter()
+    # settle how PHASE 1 looks at the sphere list (list walks, hierarchy, grid: bit-identical
+    # images) by measuring each usable path once on this scene, on a short launch
+    tune_passes = min(ppl, 8)
+    pt.tune(tune_passes)
+    tf2 = time.perf_counter()
 
     def run_steps(k, first_time, pps_use=None, spl_use=None):
         pps_use = pps_use or pps
@@ -223,6 +292,23 @@ def main():
             pt.render_passes(n * pps_use)  # asynchronous on torch's current stream
             done += n
 
+    first_frame = None
+    if not args.no_first_frame:
+        k_frame = max(1, converged_spp // spp_step)
+        run_steps(k_frame, 500.0)
+        torch.cuda.synchronize()
+        tf3 = time.perf_counter()
+        first_frame = {
+            "ms": round((tf3 - tf0) * 1e3, 2),
+            "set_scene_ms": round((tf1 - tf0) * 1e3, 2),
+            "autotune_ms": round((tf2 - tf1) * 1e3, 2),
+            "cold_frame_ms": round((tf3 - tf2) * 1e3, 2),
+            "note": "context + scene upload + structure builds + workspace; pt_tune (one cold and one measured %d-pass launch per usable "
+                    "geometry path); the first %d-spp frame with no tile-order feedback from a launch of its own shape (rank 0's share)"
+                    % (tune_passes, k_frame * spp_step),
+        }
+        pt.reset()
+
     # warmup (untimed), then clear accumulation and statistics
     run_steps(args.warmup, 1000.0)
     if use_dist:
@@ -232,7 +318,7 @@ def main():
 
     sync_all()
     t0 = time.perf_counter()
-    run_steps(args.steps, 0.0)
+    run_steps(steps, 0.0)
     full = gather(pt.accum_tensor) if use_dist else pt.accum_tensor
     sync_all()
     t1 = time.perf_counter()
@@ -251,21 +337,34 @@ def main():
     segments = float(sum(float(x[0]) for x in per_rank))
     per_rank_kernel_ms = [round(float(x[1]), 3) for x in per_rank]
 
-    # the config's own frame (1024 spp) split over the ranks: the strong-scaling point.  At N = 1, or
-    # under --scaling strong, the main region already is that workload.
-    fixed_frame = None
-    if world > 1 and args.scaling == "weak":
-        k_ff = max(1, CONVERGED_SPP // (args.spp_per_pass * pps_frame))
-        spl_ff = max(1, min(args.steps_per_launch, k_ff, ppl // pps_frame))  # within the reserved passes
+    # RCCL parity: the gathered frame against the committed single-GPU digest of the same workload
+    # (only when this run rendered exactly that workload: default sizes, passes and seeds)
+    gather_check = None
+    if rank == 0:
+        total_passes = steps * pps
+        is_digest_workload = (not weak and width == cfg["width"] and height == cfg["height"] and args.spp_per_pass == 16 and
+                              args.max_depth == 50 and total_passes * args.spp_per_pass == converged_spp)
+        want = load_digests().get(cfg["digest"]) if is_digest_workload else None
+        if want:
+            got = frame_digest(full[: p.height])
+            gather_check = {"sha256": got, "expected": want["sha256"], "key": cfg["digest"],
+                            "matches": got == want["sha256"],
+                            "segments_match": int(segments) == int(want["segments"])}
+
+    # the other scaling mode, timed after the main region with the same barriers (N > 1 only)
+    weak_series = None
+    if want_weak_series:
+        pps_w = pps_frame * world
+        k_w = min(steps, spl)
         pt.reset()
-        run_steps(k_ff, 1000.0, pps_frame, spl_ff)  # settle the tile order for this launch shape
+        run_steps(k_w, 1000.0, pps_w, spl)  # settle the tile order for this launch shape
         gather(pt.accum_tensor)
         sync_all()
         pt.reset()
         sync_all()
         f0 = time.perf_counter()
-        run_steps(k_ff, 0.0, pps_frame, spl_ff)
-        full = gather(pt.accum_tensor)
+        run_steps(k_w, 0.0, pps_w, spl)
+        gather(pt.accum_tensor)
         sync_all()
         f1 = time.perf_counter()
         sf = pt.stats()
@@ -273,19 +372,19 @@ def main():
         fseg = torch.tensor([float(sf.segments)], dtype=torch.float64, device=cdev)
         dist.all_reduce(ff, op=dist.ReduceOp.MAX)
         dist.all_reduce(fseg)
-        fixed_frame = {
-            "spp": k_ff * args.spp_per_pass * pps_frame,
+        weak_series = {
+            "spp": k_w * args.spp_per_pass * pps_w,
             "sec": round(float(ff.item()), 5),
             "value": round(float(fseg.item()) / float(ff.item()) / 1e6, 3),
             "unit": "Mray/s",
-            "scaling": "strong",
-            "note": "same frame as N = 1 (%d launches of <= %d passes over 1/%d of the rows per rank + the gather), "
-                    "barrier + synchronize on both sides, max over ranks" % ((k_ff + spl_ff - 1) // spl_ff, spl_ff * pps_frame, world),
+            "scaling": "weak",
+            "note": "per-GPU work fixed: 1/%d of the rows x %d passes per step (%d steps, one launch per rank + the gather), "
+                    "barrier + synchronize on both sides, max over ranks" % (world, pps_w, k_w),
         }
 
     if rank == 0:
         n_sph = len(sc.spheres)
-        n_passes = args.steps * pps
+        n_passes = steps * pps
         mrays = segments / wall / 1e6
         # dominant kernel: the trace kernel, timed with HIP events on its launch stream (rank 0)
         avg_ms = st.render_kernel_ms / max(st.render_launches, 1)
@@ -338,6 +437,8 @@ def main():
                 "flop_model": "lanes x (walk step %d, leaf round %d, exact %d) + segments x (%d shade/RNG/camera + %d per always-tested sphere)"
                               % (f_walk, FLOP_PER_LEAF_ROUND, FLOP_PER_EXACT, FLOP_PER_SEGMENT_SHADE, FLOP_PER_SPHERE_TEST),
                 "literal_tests_per_segment": round((4.0 * w[3]) / seg_c + n_always, 2),
+                # same passes, same seeds as the timed region when that was one launch: the twin must have shaded exactly as many segments
+                "twin_segments_equal_timed_kernel": (int(sw.segments) == int(st.segments)) if steps == spl else None,
             }
         if not walk:  # the list walks execute exactly the algorithmic work
             exec_flop_per_pass = alg_flop_per_pass
@@ -349,10 +450,34 @@ def main():
         if os.path.exists(prof):
             try:
                 rec = json.load(open(prof))
-                if rec.get("kernel") == kernel_name and rec.get("spp_per_pass") == args.spp_per_pass and rec.get("passes_per_launch") == ppl:
+                if (rec.get("kernel") == kernel_name and rec.get("spp_per_pass") == args.spp_per_pass and
+                        rec.get("passes_per_launch") == ppl and world == 1 and args.config == "2"):
                     prior = rec
             except Exception:
                 prior = None
+        counters = None
+        if prior:
+            # counter-derived figures of that PRIOR profile (profiles/summarize.py wrote them from the PMC passes):
+            #   valu_issue_frac  = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+            #   lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+            #   fp32_flop_frac   = (2 FMA + MUL) x 64 x lane_utilisation / kernel time / peak
+            lu = None
+            if prior.get("sq_thread_cycles_valu") and prior.get("sq_active_inst_valu"):
+                lu = prior["sq_thread_cycles_valu"] / (64.0 * prior["sq_active_inst_valu"])
+            ff32 = None
+            if lu and prior.get("kernel_ms") and prior.get("sq_insts_valu_fma_f32") is not None:
+                flop = (2.0 * prior["sq_insts_valu_fma_f32"] + prior.get("sq_insts_valu_mul_f32", 0.0)) * 64.0 * lu
+                ff32 = flop / (prior["kernel_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS
+            counters = {
+                "source": "PRIOR profile %s (rocprofv3 --pmc, same kernel and launch shape; not this run)" % prior.get("profile", "profiles/pmc_traffic.json"),
+                "kernel_ms": prior.get("kernel_ms"),
+                "valu_issue_frac": round(prior["valu_issue_frac"], 4) if prior.get("valu_issue_frac") else None,
+                "cycles_per_valu_per_simd": round(2.0 / prior["valu_issue_frac"], 3) if prior.get("valu_issue_frac") else None,
+                "lane_utilisation": round(lu, 4) if lu else None,
+                "fp32_flop_frac": round(ff32, 4) if ff32 else None,
+                "salu_per_valu": round(prior["sq_insts_salu"] / prior["valu_insts_per_launch"], 3) if prior.get("sq_insts_salu") and prior.get("valu_insts_per_launch") else None,
+                "lds_bank_conflict_frac": round(prior["sq_lds_bank_conflict"] / prior["sq_lds_idx_active"], 4) if prior.get("sq_lds_idx_active") else None,
+            }
         roofline = {
             "kernel": kernel_name,
             "geometry_path": abi.GEOM_NAMES.get(st.geometry_path, "?") + (" (autotuned)" if st.geometry_tuned else ""),
@@ -361,9 +486,12 @@ def main():
             "peak": FP32_VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved_tf / FP32_VALU_PEAK_TFLOPS, 4) if achieved_tf is not None else None,
+            "frac_is": "a MODEL: executed units from the measuring twin's tallies x the flop_model weights below; the counter-derived "
+                       "figure of the same kernel is counters.fp32_flop_frac",
             "traffic": prior.get("hbm_bytes_per_pass") if prior else None,
             "traffic_source": ("PRIOR profile %s (rocprofv3 --pmc WRITE_SIZE + 2*FETCH_SIZE, same kernel and launch shape), per pass"
                                % prior.get("profile", "profiles/pmc_traffic.json")) if prior else None,
+            "counters": counters,
             "per_pass": {
                 "kernel_ms": round(ms_per_pass, 4),
                 "segments": round(seg_per_pass, 1),
@@ -381,7 +509,6 @@ def main():
                      "loop (static/shader.frag:175-196) would have needed for the same rays; it exceeds 1 exactly because the walk "
                      "kernels skip tests whose outcome is provably 'miss'" % n_sph),
             "executed": executed,
-            "valu_issue_frac_prior_profile": prior.get("valu_issue_frac") if prior else None,
             "hbm": {
                 "achieved": round(hbm_bytes_per_pass / (ms_per_pass * 1e-3) / 1e9, 3) if ms_per_pass > 0 else 0.0,
                 "peak": HBM_PEAK_GBS,
@@ -395,7 +522,7 @@ def main():
         if walk and world == 1 and not args.no_list_walk:
             pt.set_geometry_path(abi.PT_GEOM_SCALAR)
             pt.reset()
-            k_lw = min(args.steps, spl)
+            k_lw = min(steps, spl)
             run_steps(k_lw, 0.0)  # settle the tile order for this path
             sync_all()
             pt.reset()
@@ -412,7 +539,7 @@ def main():
                 "value": round(sl.segments / (tl1 - tl0) / 1e6, 3),
                 "unit": "Mray/s",
                 "steps": k_lw,
-                "sec_to_converged_frame": round((tl1 - tl0) / k_lw * (CONVERGED_SPP / spp_step), 4),
+                "sec_to_converged_frame": round((tl1 - tl0) / k_lw * (converged_spp / spp_step), 4),
                 "kernel_ms_per_pass": round(l_ms_pass, 4),
                 "roofline_frac": round(l_tf / FP32_VALU_PEAK_TFLOPS, 4),
                 "note": "every sphere tested for every ray, as static/shader.frag:175-196 does; same image bits, same segment "
@@ -437,6 +564,7 @@ def main():
                 "unit": "Mray/s",
                 "cores": cores,
                 "kind": "port",
+                "algorithm": "linear list walk (static/shader.frag:175-196), scalar code, pthread workers over rows",
                 "build": flags,
                 "native_build": native,
                 "sample": "one %d-spp pass of the centre %dx%d column strip of the same frame (%d segments, %.1f s)"
@@ -448,29 +576,33 @@ def main():
             "unit": "Mray/s",
             "n_gpus": world,
             "ranks": ranks_seen,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "ms_per_step": round(wall / steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "config2: Shirley cover scene (%d spheres), %dx%d, %d bounces, %d spp/step (%d passes x %d spp) x %d steps = %d spp"
-                            % (n_sph, p.width, p.height, args.max_depth, spp_step, pps, args.spp_per_pass, args.steps, spp_step * args.steps),
+                "workload": "%s: Shirley cover scene (%d spheres), %dx%d, %d bounces, %d spp/step (%d passes x %d spp) x %d steps = %d spp"
+                            % (cfg["name"], n_sph, p.width, p.height, args.max_depth, spp_step, pps, args.spp_per_pass, steps, spp_step * steps),
                 "partition": "%d rank(s), interleaved %d-row bands, one all_gather at the end of the timed region%s"
                              % (world, band_rows, "; per-GPU work fixed: 1/%d of the rows x %d passes per step" % (world, pps)
-                                if (world > 1 and args.scaling == "weak") else ""),
+                                if weak else ("; the same frame for every N" if world > 1 else "")),
                 "steps_per_launch": spl,
                 "passes_per_launch": ppl,
                 "spp_per_pass": args.spp_per_pass,
             },
-            "sec_to_converged_frame": fixed_frame["sec"] if fixed_frame else round(wall / args.steps * (CONVERGED_SPP / spp_step), 4),
-            "fixed_frame": fixed_frame,
-            "converged_frame_spp": CONVERGED_SPP,
+            "sec_to_converged_frame": round(wall / steps * (converged_spp / spp_step), 4),
+            "converged_frame_spp": converged_spp,
+            "gather_matches_single_gpu": gather_check["matches"] if gather_check else None,
+            "gather_check": gather_check,
+            "weak_series": weak_series,
+            "first_frame_ms": first_frame["ms"] if first_frame else None,
+            "first_frame": first_frame,
             "segments": int(segments),
-            "nominal_mray_s": round(p.width * p.height * spp_step * args.steps * args.max_depth / wall / 1e6, 1),
+            "nominal_mray_s": round(p.width * p.height * spp_step * steps * args.max_depth / wall / 1e6, 1),
             "per_rank_render_kernel_ms": per_rank_kernel_ms,
             "roofline": roofline,
             "list_walk": list_walk,
@@ -478,12 +610,30 @@ def main():
         }
         if cpu:
             out["gpu_over_cpu"] = round(mrays / cpu["value"], 1) if cpu["value"] else None
+            out["list_walk_over_cpu"] = round(list_walk["value"] / cpu["value"], 1) if (list_walk and cpu["value"]) else None
+            out["gpu_over_cpu_note"] = ("gpu_over_cpu divides the fastest GPU path (culling structure) by a CPU that walks the whole list; "
+                                        "list_walk_over_cpu is like for like (both test every sphere)")
         print(json.dumps(out), flush=True)
         assert tuple(full.shape) == (p.height, p.width, 4)
     pt.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def frame_loop_bench(args):
+    """--config default: the reference at its OWN operating point.  State::default (9 spheres, at most
+    15 by static/shader.frag:103), 1280x702 (images/14.png; MAX_CANVAS_SIZE 1280, src/dom.rs:13),
+    depth 8, one 1-spp frame per animation tick blended into RGBA8 ping-pong textures by the
+    shader's render() rule (src/state.rs:127-135, src/lib.rs:65-104, src/webgl.rs:180-205) —
+    app.FrameLoop's "reference" mode, with the per-frame work (trace + fold + blend) replayed from
+    hipGraphs.  A step is one frame; `value` is frames per second, with Mray/s beside it; the
+    25-spp paused mode (src/webgl.rs:342-346) is timed beside it."""
+    from ray_tracer_webgl_amd.app import frame_loop_benchmark
+
+    out = frame_loop_benchmark(args.frames, args.warmup)
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def build_native_oracle():

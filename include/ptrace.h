@@ -299,6 +299,10 @@ int pt_build_bvh(const PtSphere* spheres, uint32_t n, float* nodes, size_t node_
 int pt_build_grid(const PtSphere* spheres, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
                   float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
                   uint32_t* entry_index, size_t n_index);
+/* What the grid kernels' entry test and cell look-up read beside geom12 / margin4 (tests emulate the
+ * kernel's walk on the host with exactly these): out10 = {r2_near: rays with |o - c0|^2 <= it walk the
+ * cells; lo_n.xyz, hi_n.xyz: the grid's box widened for the rounding of the slab test; inv_h.xyz}. */
+int pt_grid_walk_constants(const PtSphere* spheres, uint32_t n, float* out10);
 const char* pt_last_error(pt_ctx* ctx); /* ctx may be NULL: last create-time error */
 int pt_abi_version(void);
 int pt_device_count(void);

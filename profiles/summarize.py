@@ -91,8 +91,13 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
         rec["valu_insts_per_launch"] = pm["SQ_INSTS_VALU"]
         rec["kernel_cycles"] = cycles
         rec["valu_issue_frac"] = 2.0 * pm["SQ_INSTS_VALU"] / (1024.0 * cycles)
-        for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES"):
+        for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_LDS_BANK_CONFLICT",
+                  "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"):
             if k in pm:
                 rec[k.lower()] = pm[k]
+    # the same kernel's average duration in the kernel-trace pass of the same command
+    ks = out.get("kernel_stats", {}).get(out.get("pmc_kernel"))
+    if ks:
+        rec["kernel_ms"] = ks["avg_ms"]
     json.dump(rec, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)

@@ -43,6 +43,7 @@ SIGNATURES = {
                                _vp, C.c_size_t, C.POINTER(C.c_float), _vp, C.c_size_t]),
     "pt_build_grid": (C.c_int, [C.POINTER(abi.PtSphere), C.c_uint32, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, C.c_size_t,
                                 _vp, C.c_size_t, _vp, C.c_size_t]),
+    "pt_grid_walk_constants": (C.c_int, [C.POINTER(abi.PtSphere), C.c_uint32, _vp]),
     "pt_last_error": (C.c_char_p, [_ctx]),
     "pt_abi_version": (C.c_int, []),
     "pt_device_count": (C.c_int, []),

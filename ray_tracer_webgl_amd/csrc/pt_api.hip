@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/ptrace.h"
+#include "../../include/ptrace_dev.h"
 #include "pt_bvh.hpp"
 #include "pt_grid.hpp"
 #include "pt_kernel_args.h"
@@ -504,6 +505,7 @@ PT_API int pt_set_params(pt_ctx* c, const PtParams* p) {
     // a different set of rows: the accumulated image no longer applies
     PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
     c->total_spp = 0;
+    c->captured = false;  // whatever a replayed graph accumulated is gone with the old partition
   }
   c->params = *p;
   c->have_params = true;
@@ -598,14 +600,29 @@ PT_API int pt_load_accum(pt_ctx* c, const float* src, size_t bytes) {
   if (bytes != need)
     return fail(c, PT_ERR_INVALID, "pt_load_accum: %zu bytes, the current row partition holds %zu", bytes, need);
   PT_HIP(c, hipSetDevice(c->device));
-  if (need) PT_HIP(c, hipMemcpyAsync(c->accum, src, need, hipMemcpyDefault, c->stream));
+  if (need == 0) return PT_OK;
+  // validate first, commit afterwards (like pt_set_params): the checkpoint is staged in the read-out
+  // buffer, its sample count — the .w every pixel carries; a pass adds the same spp to all of them, so
+  // the first and the last pixel must agree — is checked there, and only then does it replace the
+  // accumulation.  A refused checkpoint leaves the context as it was.
+  const size_t n_pix = (size_t)c->local_rows * c->width;
+  PT_HIP(c, hipMemcpyAsync(c->d_resolve, src, need, hipMemcpyDefault, c->stream));
+  float4 ends[2];
+  PT_HIP(c, hipMemcpyAsync(&ends[0], c->d_resolve, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  PT_HIP(c, hipMemcpyAsync(&ends[1], c->d_resolve + (n_pix - 1), sizeof(float4), hipMemcpyDeviceToHost, c->stream));
   PT_HIP(c, hipStreamSynchronize(c->stream));
-  // the spp count travels in the buffer (the .w of every pixel); mirror it on the host
-  float4 px0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (need) PT_HIP(c, hipMemcpy(&px0, c->accum, sizeof px0, hipMemcpyDeviceToHost));
-  if (!(px0.w >= 0.0f) || px0.w >= 16777216.0f)
-    return fail(c, PT_ERR_INVALID, "pt_load_accum: sample count %g in the buffer is not a count", (double)px0.w);
-  c->total_spp = (uint32_t)px0.w;
+  const float w = ends[0].w;
+  if (!(w >= 0.0f) || w >= 16777216.0f || w != std::floor(w))
+    return fail(c, PT_ERR_INVALID, "pt_load_accum: sample count %g in the buffer is not a count", (double)w);
+  if (ends[1].w != w)
+    return fail(c, PT_ERR_INVALID, "pt_load_accum: sample counts differ across the buffer (%g ... %g): not an accumulation of whole passes",
+                (double)w, (double)ends[1].w);
+  PT_HIP(c, hipMemcpyAsync(c->accum, c->d_resolve, need, hipMemcpyDeviceToDevice, c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  // the host-side mirrors follow the loaded state
+  c->total_spp = (uint32_t)w;
+  c->samples = (uint64_t)w * (uint64_t)n_pix;
+  c->captured = false;
   return PT_OK;
 }
 
@@ -739,15 +756,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
         A.grid_h[k] = g.h[k]; A.grid_inv_h[k] = g.inv_h[k];
       }
       A.bvh_s0 = g.s0;
-      {
-        const double rn = 0.9999 * (double)g.d_near - (double)g.s0;
-        A.grid_r2_near = ptgrid::round_down(rn * rn * (1.0 - 1e-6));
-        const double widen = 1e-6 * (double)g.d_near + 1e-30;
-        for (int k = 0; k < 3; k++) {
-          A.grid_lo_n[k] = ptgrid::round_down((double)g.lo[k] - widen);
-          A.grid_hi_n[k] = ptgrid::round_up((double)g.hi[k] + widen);
-        }
-      }
+      A.grid_r2_near = g.r2_near;
+      for (int k = 0; k < 3; k++) { A.grid_lo_n[k] = g.lo_n[k]; A.grid_hi_n[k] = g.hi_n[k]; }
       const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
       const size_t need_all = need_cells + (size_t)g.n_entries * 16;
       if (need_all + park1024 <= lds_max) {
@@ -825,6 +835,13 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
   if (grid < 1) grid = 1;
 
+  // inside a stream capture (hipGraph) nothing may synchronise or allocate and timing events are
+  // meaningless: the launch sequence itself is capture-safe, the measuring twins' set-up is not
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(c->stream, &cap);
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (capturing && c->count_work)
+    return fail(c, PT_ERR_INVALID, "pt_render_passes: PT_OPT_COUNT_WORK (measuring twin: allocates its wave log) cannot be captured into a hipGraph");
   A.wave_log = nullptr;
   if (c->count_work && (path == PT_GEOM_BVH || path == PT_GEOM_GRID)) { // measuring twin: not a product launch, may allocate
     const size_t n_waves = (size_t)grid * (block / 64);
@@ -838,11 +855,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     c->wave_log_n = n_waves;
     A.wave_log = c->d_wave_log;
   }
-  // inside a stream capture (hipGraph) nothing may synchronise and timing events are
-  // meaningless: skip the event pair, the launch sequence itself is capture-safe
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(c->stream, &cap);
-  const bool capturing = cap != hipStreamCaptureStatusNone;
+  // (capturing: skip the timing event pair)
   if (!capturing && c->events_used == c->events.size()) {
     if (c->events.size() >= 512) {
       // pool full: drain (this synchronises, but only once per 512 launches)
@@ -902,7 +915,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
 
 
-extern "C" __attribute__((visibility("default"))) long pt_debug_counters(pt_ctx* c, unsigned long long* out, size_t cap) {
+// ---- include/ptrace_dev.h: developer diagnostics, not part of the versioned ABI ----------------
+PT_API long pt_debug_counters(pt_ctx* c, unsigned long long* out, size_t cap) {
   if (!c || !out) return -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
   const size_t n = cap < (size_t)PT_CTR_COUNT ? cap : (size_t)PT_CTR_COUNT;
@@ -912,7 +926,7 @@ extern "C" __attribute__((visibility("default"))) long pt_debug_counters(pt_ctx*
 
 // Dev diagnostics of the measuring twins: per wave {start, queue dry (0 = never saw it dry), end}
 // of the last counted launch, in 100 MHz ticks.  Returns the number of waves, or < 0.
-extern "C" __attribute__((visibility("default"))) long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_waves) {
+PT_API long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_waves) {
   if (!c || !c->d_wave_log || !out) return -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
   const size_t n = c->wave_log_n < cap_waves ? c->wave_log_n : cap_waves;

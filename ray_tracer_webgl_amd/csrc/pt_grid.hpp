@@ -80,6 +80,12 @@ struct Grid {
   float s0 = 0, rmin = 0, rmax = 0;
   float d_near = 0;   // rays with |o - c0|_2 + s0 <= d_near may walk the cells
   float delta_g = 0;  // registration inflation
+  // what the kernel's entry test uses (made here so that the kernel launch and the host emulation
+  // of tests/test_grid.py read the same numbers): near rays are those with |o - c0|^2 <= r2_near
+  // = ((0.9999 d_near - s0)^2, rounded down); they test the slab [lo_n, hi_n] = [lo, hi] widened by
+  // 1e-6 (d_near + |c0|_inf) for the rounding of the slab arithmetic, which runs in ABSOLUTE
+  // coordinates (fma(plane, 1/d, -(o * 1/d)): position error ~ 2u (|c0| + d_near))
+  float r2_near = 0, lo_n[3] = {0, 0, 0}, hi_n[3] = {0, 0, 0};
   uint32_t max_cell_entries = 0, nonempty = 0;
 };
 
@@ -211,8 +217,9 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     // weakly, on the resolution and the extent): iterate to a fixed point
     for (int pass = 0; pass < 16; pass++) {
       diag = 0.0; n_sum = 0; ok = true;
+      const double dgr = (double)round_up(dg);  // the inflation as it is stored (delta_g): boxes registered with it stay inside [lo, hi]
       for (int k = 0; k < 3; k++) {
-        const double a = blo[k] - dg, b = bhi[k] + dg;
+        const double a = blo[k] - dgr, b = bhi[k] + dgr;
         double cells = std::floor((b - a) / edge + 0.5);
         if (cells < 1.0) cells = 1.0;
         if (cells > (double)kMaxAxis) { ok = false; cells = kMaxAxis; }
@@ -226,7 +233,10 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
       }
       diag = std::sqrt(diag);
       const double u = 5.9604644775390625e-08;
-      const double eps_dda = 32.0 * (n_sum + 8.0) * u * ((double)g.d_near + diag);
+      // the walk's plane times are evaluated in absolute coordinates, so their position error scales
+      // with |c0| + d_near (a scene centred far from the origin), not with d_near alone
+      const double c0abs = std::max(std::fabs((double)g.c0[0]), std::max(std::fabs((double)g.c0[1]), std::fabs((double)g.c0[2])));
+      const double eps_dda = 32.0 * (n_sum + 8.0) * u * ((double)g.d_near + diag + c0abs);
       // the kernel's per-ray delta carries 25 % slack on E' and is compared against this value
       const double need = (std::sqrt(rmin * rmin + 32.0 * 1.25 * u * (double)g.d_near * g.d_near) - rmin + 16.0 * u * rmax) + eps_dda;
       if (need <= dg) break;
@@ -297,6 +307,16 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     }
     g.n_entries = (uint32_t)g.entry_index.size();
     if (g.n_entries > (1u << 24)) return false;
+    {
+      const double c0abs = std::max(std::fabs((double)g.c0[0]), std::max(std::fabs((double)g.c0[1]), std::fabs((double)g.c0[2])));
+      const double rn = 0.9999 * (double)g.d_near - (double)g.s0;
+      g.r2_near = round_down(rn * rn * (1.0 - 1e-6));
+      const double widen = 1e-6 * ((double)g.d_near + c0abs) + 1e-30;
+      for (int k = 0; k < 3; k++) {
+        g.lo_n[k] = round_down((double)g.lo[k] - widen);
+        g.hi_n[k] = round_up((double)g.hi[k] + widen);
+      }
+    }
     *out = std::move(g);
     return true;
   }

@@ -1,0 +1,241 @@
+// pt_grid_walk.hpp — PHASE 1 of hit_world through the uniform grid of pt_grid.hpp (PT_GEOM_GRID):
+// which spheres a ray LOOKS AT.  Every entry that is looked at runs the LITERAL test (sphere_test +
+// hit_root), so only the skipping needs an argument.
+//
+// EXACTNESS ARGUMENT.  The ORDER in which spheres are looked at is free and spheres that cannot
+// pass need not be looked at (pt_list.hpp).  A sphere can be hit only at a point within delta of its
+// surface (error analysis in pt_grid.hpp), hence inside its bounding box inflated by delta; the
+// grid registers every sphere in all cells that box touches (inflation delta_g: the bound for rays
+// that start within d_near of the scene's middle, plus the rounding of this walk), so a ray only
+// has to look at the entries of the cells it passes through — in order, which lets it stop as soon
+// as the closest accepted root lies STRICTLY before the exit of the cell just finished (whatever
+// is registered only in later cells has a later root; equal roots are resolved by list index
+// whatever the entry order, and a sphere met again in a second cell meets itself).  Far-out
+// giants and spheres much larger than a cell are not gridded: every ray tests them first, through
+// scalar loads / LDS broadcasts.  The rare ray from farther away than d_near tests the grid's box
+// inflated by its own delta(D); if it enters, the lane takes the literal loop over the whole list.
+// Host-side check of the claim (registration invariant, the bound, a numpy emulation of this walk
+// against brute force): tests/test_grid.py.
+#pragma once
+#include "pt_scene.hpp"
+
+namespace ptk {
+
+template <typename S, bool COUNT>
+__device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, bool scan_lane, int n_live, Carry& cw,
+                                          GridWalk& w, Hit& h, Tally<COUNT>& tally) {
+  karg_t& K = *kargs();
+  const V3& o = p.o; const V3& d = p.d; const float a = p.a;
+  float& closest = h.closest; int& hit = h.hit; uint32_t& lit_from = h.lit_from;
+  bool& carried = cw.carried; uint32_t& hit_pos = cw.hit_pos;
+  float& tmx = w.tmx; float& tmy = w.tmy; float& tmz = w.tmz; float& t_exit = w.t_exit;
+  uint32_t& cell = w.cell; uint32_t& rem = w.rem; uint32_t& pend = w.pend; bool& gactive = w.gactive;
+  const uint32_t n_cell_entries = A.n_tree_slots;
+  const bool fresh = scan_lane && !carried;
+  const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
+  const uint32_t a_guard = hit_root_guard(a);
+
+  // exact part of hit_sphere for the candidates of ONE group of four entries (4-bit mask),
+  // all lanes in lockstep: max-over-lanes(popcount) ~ 1-2 evaluations per group
+  auto exact_group = [&](uint32_t base, uint32_t& mask, float hb0, float hb1, float hb2, float hb3, float ds0, float ds1,
+                         float ds2, float ds3) {
+    for (;;) {
+      const unsigned long long m_x = pt_ballot(mask != 0u);
+      if (m_x == 0ull) break;
+      tally.exact(m_x);
+      if (mask != 0u) {
+        const uint32_t k = (uint32_t)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
+        const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));
+        const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161
+        const uint32_t pos = base + k;
+        // order-free acceptance: smaller root wins, equal roots go to the LATER sphere of the
+        // list; indices are only looked up for the rare exact tie (a sphere registered in two
+        // cells meets ITSELF again: same index, no change)
+        bool wins = v < closest;
+        if (v == closest)
+          wins = hit_pos == 0xffffffffu || A.bvh_slot_index[pos] > A.bvh_slot_index[hit_pos];
+        if (!(v < PT_MIN_T) && wins) {
+          closest = v;
+          hit_pos = pos;
+        }
+      }
+    }
+  };
+  // the literal test passes (:153) and the sphere is not behind the ray
+  auto passes = [](float hb, float cc, float ds) -> bool { return !(ds < 0.0f) && !(cc > 0.0f && hb >= 0.0f); };
+
+  // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is
+  // padded with entries that never pass); carried lanes have done this
+  {
+    const uint32_t n_grp = (A.n_outliers + 3u) >> 2;
+    for (uint32_t gi = 0; gi < n_grp; gi++) {
+      const uint32_t base = n_cell_entries + 4u * gi;
+      // wave-uniform index: an LDS broadcast where the entries are staged, scalar loads otherwise
+      float4 e0, e1, e2, e3;
+      if constexpr (S::WALK == 4) {
+        e0 = S::slot_at(A, base); e1 = S::slot_at(A, base + 1u); e2 = S::slot_at(A, base + 2u); e3 = S::slot_at(A, base + 3u);
+      } else {
+        const f4v s0 = S::c_slots(A)[base], s1 = S::c_slots(A)[base + 1u], s2 = S::c_slots(A)[base + 2u], s3 = S::c_slots(A)[base + 3u];
+        e0 = make_float4(s0.x, s0.y, s0.z, s0.w); e1 = make_float4(s1.x, s1.y, s1.z, s1.w);
+        e2 = make_float4(s2.x, s2.y, s2.z, s2.w); e3 = make_float4(s3.x, s3.y, s3.z, s3.w);
+      }
+      float hb0, cc0, ds0; sphere_test(o, d, a, e0, hb0, cc0, ds0);
+      float hb1, cc1, ds1; sphere_test(o, d, a, e1, hb1, cc1, ds1);
+      float hb2, cc2, ds2; sphere_test(o, d, a, e2, hb2, cc2, ds2);
+      float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
+      uint32_t mask = 0u;
+      if (fresh)
+        mask = (passes(hb0, cc0, ds0) ? 1u : 0u) | (passes(hb1, cc1, ds1) ? 2u : 0u) |
+               (passes(hb2, cc2, ds2) ? 4u : 0u) | (passes(hb3, cc3, ds3) ? 8u : 0u);
+      exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
+    }
+  }
+
+  // per-ray constants of the walk (recomputed for carried lanes: cheaper than keeping them)
+  const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f);
+  const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f);
+  const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f);
+  const bool posx = ix > 0.0f, posy = iy > 0.0f, posz = iz > 0.0f;
+  const float tdx = K.grid_h[0] * __builtin_fabsf(ix), tdy = K.grid_h[1] * __builtin_fabsf(iy),
+              tdz = K.grid_h[2] * __builtin_fabsf(iz);
+  const int gnx = (int)K.grid_n[0], gny = (int)K.grid_n[1], gnz = (int)K.grid_n[2];
+  const int sdx = posx ? 1 : -1;
+  const int sdy = posy ? gnx : -gnx;
+  const int sdz = posz ? gnx * gny : -(gnx * gny);
+
+  // entry: where does the half-line meet the grid's box?
+  if (!carried) { gactive = false; pend = 0u; }
+  if (pt_ballot(fresh) != 0ull) {
+    // near rays (|o - c0| + s0 <= d_near, tested on squares: grid_r2_near = (0.9999 d_near - s0)^2):
+    // every registered box lies inside [lo, hi] (delta_g is part of it); the host has widened
+    // grid_lo_n / grid_hi_n by 1e-6 d_near for the rounding of this slab arithmetic.  Far
+    // rays test the box inflated by their own delta(D) <= sqrt(40 u) D + 16 u rmax < 1.7e-3 D;
+    // if they enter they take the literal loop (PHASE 3) over the whole list.
+    const float px = o.x - K.bvh_c0[0], py = o.y - K.bvh_c0[1], pz = o.z - K.bvh_c0[2];
+    const float r2 = fma_(pz, pz, fma_(py, py, px * px));
+    const bool near = r2 <= K.grid_r2_near;
+    float mm = 0.0f;
+    if (pt_ballot(fresh && !near) != 0ull) // (rare) v_sqrt_f32 is good to 1 ulp, the factor carries 10 % slack
+      mm = near ? 0.0f : 1.7e-3f * (__builtin_amdgcn_sqrtf(r2) + K.bvh_s0);
+    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+    const float t1x = fma_(K.grid_lo_n[0] - mm, ix, -oix), t2x = fma_(K.grid_hi_n[0] + mm, ix, -oix);
+    const float t1y = fma_(K.grid_lo_n[1] - mm, iy, -oiy), t2y = fma_(K.grid_hi_n[1] + mm, iy, -oiy);
+    const float t1z = fma_(K.grid_lo_n[2] - mm, iz, -oiz), t2z = fma_(K.grid_hi_n[2] + mm, iz, -oiz);
+    const float tn = __builtin_fmaxf(
+        __builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)),
+        __builtin_fmaxf(__builtin_fminf(t1z, t2z), 0.0f));
+    const float tf = __builtin_fminf(
+        __builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)),
+        __builtin_fmaxf(t1z, t2z));
+    bool enter = fresh && tn <= __builtin_fminf(tf, closest);
+    if (enter && !near) { // (rare) a ray from far away that does reach the grid
+      lit_from = 0u;
+      closest = PT_MAX_T;
+      hit_pos = 0xffffffffu;
+      enter = false;
+    }
+    if (enter) {
+      gactive = true;
+      // the cell that holds the entry point (clamped: rounding may put it a hair outside)
+      const float glx = K.grid_lo[0], gly = K.grid_lo[1], glz = K.grid_lo[2];
+      const float ghx = K.grid_h[0], ghy = K.grid_h[1], ghz = K.grid_h[2];
+      const float fx = (fma_(d.x, tn, o.x) - glx) * K.grid_inv_h[0];
+      const float fy = (fma_(d.y, tn, o.y) - gly) * K.grid_inv_h[1];
+      const float fz = (fma_(d.z, tn, o.z) - glz) * K.grid_inv_h[2];
+      const int nx1 = gnx - 1, ny1 = gny - 1, nz1 = gnz - 1;
+      int cx = (int)__builtin_floorf(fx), cy = (int)__builtin_floorf(fy), cz = (int)__builtin_floorf(fz);
+      cx = cx < 0 ? 0 : (cx > nx1 ? nx1 : cx);
+      cy = cy < 0 ? 0 : (cy > ny1 ? ny1 : cy);
+      cz = cz < 0 ? 0 : (cz > nz1 ? nz1 : cz);
+      // times at which the ray crosses the cell's far planes (the side follows the sign of
+      // the CLAMPED reciprocal, so a zero component gets a plane it never reaches: +-1e18 times
+      // a non-negative distance) — never before the entry time
+      const float bx = fma_((float)(cx + (posx ? 1 : 0)), ghx, glx);
+      const float by = fma_((float)(cy + (posy ? 1 : 0)), ghy, gly);
+      const float bz = fma_((float)(cz + (posz ? 1 : 0)), ghz, glz);
+      tmx = __builtin_fmaxf(fma_(bx, ix, -oix), tn);
+      tmy = __builtin_fmaxf(fma_(by, iy, -oiy), tn);
+      tmz = __builtin_fmaxf(fma_(bz, iz, -oiz), tn);
+      // steps left before the walk leaves the grid, + 1, three 10-bit fields
+      rem = (uint32_t)((posx ? nx1 - cx : cx) + 1) | ((uint32_t)((posy ? ny1 - cy : cy) + 1) << 10) |
+            ((uint32_t)((posz ? nz1 - cz : cz) + 1) << 20);
+      cell = ((uint32_t)cz * (uint32_t)gny + (uint32_t)cy) * (uint32_t)gnx + (uint32_t)cx;
+    }
+  }
+
+  tally.phase(2);
+  uint32_t walk_iters = 0;
+  for (;;) {
+    // advance: a lane without a cell under test looks at the cell it stands in, notes its
+    // exit time, and steps on; it leaves this loop with a non-empty cell or with its walk over
+    for (;;) {
+      const bool mv = gactive && (pend >> 24) == 0u;
+      const unsigned long long m_mv = pt_ballot(mv);
+      if (m_mv == 0ull) break;
+      tally.walk(m_mv);
+      if (mv) {
+        const uint32_t rec = S::cell_at(A, cell);
+        const float tmin = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
+        const bool isx = tmx == tmin;
+        const bool isy = !isx && tmy == tmin;
+        const bool isz = !isx && !isy;
+        t_exit = tmin;
+        pend = rec;
+        tmx += isx ? tdx : 0.0f;
+        tmy += isy ? tdy : 0.0f;
+        tmz += isz ? tdz : 0.0f;
+        const uint32_t dec = isx ? 1u : (isy ? 1024u : 1048576u);
+        rem -= dec;
+        const bool out = (rem & (dec * 1023u)) == 0u;
+        cell += (uint32_t)(isx ? sdx : (isy ? sdy : sdz));
+        // the walk is over when it leaves the grid — or, on an empty cell, when the closest
+        // root so far lies strictly before this cell's exit (a non-empty cell asks again
+        // after its entries have been tested)
+        if (out || ((rec >> 24) == 0u && closest < tmin)) gactive = false;
+      }
+    }
+    tally.phase(3);
+    const bool has = (pend >> 24) != 0u;
+    const unsigned long long m_has = pt_ballot(has);
+    if (m_has == 0ull) break; // no cell under test and nobody can move: every walk is over
+    tally.leaf(m_has);
+    {
+      // four consecutive entries of the cell under test (those beyond its count belong to the
+      // next cell or to the slack behind the array: tested, then masked)
+      const uint32_t base = pend & 0xffffffu;
+      const uint32_t left = pend >> 24;
+      const float4 g0 = S::slot_at(A, base), g1 = S::slot_at(A, base + 1u), g2 = S::slot_at(A, base + 2u), g3 = S::slot_at(A, base + 3u);
+      float hb0, cc0, ds0; sphere_test(o, d, a, g0, hb0, cc0, ds0);
+      float hb1, cc1, ds1; sphere_test(o, d, a, g1, hb1, cc1, ds1);
+      float hb2, cc2, ds2; sphere_test(o, d, a, g2, hb2, cc2, ds2);
+      float hb3, cc3, ds3; sphere_test(o, d, a, g3, hb3, cc3, ds3);
+      uint32_t mask = 0u;
+      if (has) {
+        mask = (passes(hb0, cc0, ds0) ? 1u : 0u) | (passes(hb1, cc1, ds1) ? 2u : 0u) |
+               (passes(hb2, cc2, ds2) ? 4u : 0u) | (passes(hb3, cc3, ds3) ? 8u : 0u);
+        mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
+        pend = left > 4u ? (base + 4u) | ((left - 4u) << 24) : 0u;
+      }
+      exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
+      // the cell is done: can anything registered only in later cells still win?
+      if (has && (pend >> 24) == 0u && closest < t_exit) gactive = false;
+    }
+    tally.phase(4);
+    walk_iters++;
+    const unsigned long long m_on = pt_ballot(gactive || (pend >> 24) != 0u);
+    if (m_on == 0ull) break;
+    const uint32_t n_on = (uint32_t)__popcll(m_on);
+    // carry the stragglers: the longer this step's walk has run, the more lanes may be left behind
+    // (a long walk means a scene of long walks, where waiting for the last quarter of the lanes costs
+    // more than shading at three quarters; short walks never get past the base threshold)
+    if (walk_iters >= 2u && A.carry_lanes != 0u && n_on < A.carry_lanes + 4u * (walk_iters - 2u) &&
+        2u * n_on < (uint32_t)n_live) break;
+  }
+  carried = gactive || (pend >> 24) != 0u;
+  tally.carried(carried);
+  if (hit_pos != 0xffffffffu) hit = 0; // a hit; shading reads the slot's own copies (index not needed)
+}
+
+} // namespace ptk

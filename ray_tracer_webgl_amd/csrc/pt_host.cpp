@@ -161,6 +161,29 @@ PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float
   return PT_OK;
 }
 
+// The numbers the grid kernels' ENTRY test and cell look-up use beside geom12 / margin4 of
+// pt_build_grid (made by ptgrid::build, copied into the launch arguments by pt_render_passes):
+// out10 = {r2_near, lo_n.xyz, hi_n.xyz, inv_h.xyz}.
+PT_API int pt_grid_walk_constants(const PtSphere* s, uint32_t n, float* out10) {
+  if ((!s && n) || !out10) return PT_ERR_INVALID;
+  std::vector<float> geom((size_t)n * 4), radii(n);
+  bool regular = true;
+  for (uint32_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) {
+      regular = regular && (std::fabs(s[i].center[k]) < 1e15f);
+      geom[4 * (size_t)i + k] = s[i].center[k];
+    }
+    regular = regular && (std::fabs(s[i].radius) < 1e15f);
+    geom[4 * (size_t)i + 3] = s[i].radius * s[i].radius;
+    radii[i] = s[i].radius;
+  }
+  ptgrid::Grid g;
+  if (!regular || !ptgrid::build(geom.data(), radii.data(), n, &g)) return PT_ERR_NOT_READY;
+  out10[0] = g.r2_near;
+  for (int k = 0; k < 3; k++) { out10[1 + k] = g.lo_n[k]; out10[4 + k] = g.hi_n[k]; out10[7 + k] = g.inv_h[k]; }
+  return PT_OK;
+}
+
 PT_API int pt_build_bvh(const PtSphere* s, uint32_t n, float* nodes, size_t node_floats, float* slots,
                         size_t slot_floats, uint32_t* slot_index, size_t n_index, float* margin4,
                         uint32_t* counts5, uint32_t* nodes16, size_t n_words16, float* kscale,

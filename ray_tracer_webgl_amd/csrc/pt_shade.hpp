@@ -1,0 +1,152 @@
+// pt_shade.hpp — what happens at the end of a segment: static/shader.frag:304-338 (miss ->
+// background :289-294, hit -> hit record :166-171, front face :136-143, scatter :210-286,
+// depth bookkeeping :300,:338) and the end-of-item store.
+//
+// EXACTNESS ARGUMENT carried by this file: the outward normal's three divisions by the radius use
+// div_core under a per-lane range guard (|radius| in [2^-20, 2^20), every numerator with
+// 2^-103 <= |n| < 2^76; a zero numerator takes the plain operator because its quotient's sign of
+// zero comes from v_div_fixup); everything else is the oracle's operation order, statement by
+// statement.  RNG draws happen exactly where the shader draws them (one random_in_unit_sphere for
+// DIFFUSE :217 and METAL :240 alike — also when fuzz is 0 —, one hash1 for GLASS :267).
+#pragma once
+#include "pt_scene.hpp"
+
+namespace ptk {
+
+// shade the lanes whose walk / scan has finished (`p.alive && !carried`): the closest hit is
+// (h.closest, h.hit) — walk kernels: the slot cw.hit_pos, whose copy of the sphere and of its
+// material record are read instead of going through the list index
+template <typename S>
+__device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, const Hit& h, const Carry& cw) {
+  bool& alive = p.alive; bool& new_path = p.new_path;
+  const uint32_t slab_index = p.slab_index; const uint32_t item_tile = p.item_tile; uint32_t& item_segs = p.item_segs;
+  int& sample = p.sample; int& depth = p.depth; float& seed = p.seed;
+  V3& o = p.o; V3& d = p.d; float& a = p.a; V3& col = p.col; V3& sum = p.sum;
+  const float closest = h.closest; const int hit = h.hit; const uint32_t hit_pos = cw.hit_pos;
+  (void)hit_pos;
+  item_segs++;
+  bool finished = false; // this camera path is over
+  if (hit < 0) {
+    if (A.background_mode == 0) { // background(), :289-294
+      float inv = inv_sqrt_rn(a);
+      float uy = d.y * inv;
+      float t = 0.5f * (uy + 1.0f);
+      float omt = 1.0f - t;
+      sum.x += col.x * fma_(0.5f, t, omt);
+      sum.y += col.y * fma_(0.7f, t, omt);
+      sum.z += col.z * fma_(1.0f, t, omt);
+    }
+    finished = true;
+  } else {
+    float4 g;
+    if constexpr (S::TREE) { // the walk's hits come with their slot (same four floats as the list entry)
+      if (hit_pos != 0xffffffffu) g = S::slot_at(A, hit_pos);
+      else g = S::geom_at(A, (uint32_t)hit);
+    } else {
+      g = S::geom_at(A, (uint32_t)hit);
+    }
+    const float4* mp = reinterpret_cast<const float4*>(A.mat + hit);
+    if constexpr (S::TREE) { // one load instead of index -> material (two dependent memory round trips)
+      if (hit_pos != 0xffffffffu) mp = reinterpret_cast<const float4*>(A.slot_mat + hit_pos);
+    }
+    float4 m0 = mp[0]; // albedo.xyz, fuzz
+    float4 m1 = mp[1]; // refraction_index, type, radius, uuid
+    int mtype = __float_as_int(m1.y);
+    float radius = m1.z;
+    // hit record, :166-171
+    V3 p = mk(fma_(d.x, closest, o.x), fma_(d.y, closest, o.y), fma_(d.z, closest, o.z));
+    // outward normal (p - centre) / radius, :168: three divisions by one denominator.  Fast form
+    // when |radius| is in [2^-20, 2^20) and every numerator has 2^-103 <= |n| < 2^76 (a zero
+    // numerator takes the plain operator: its quotient's sign of zero comes from v_div_fixup)
+    const float nx = p.x - g.x, ny = p.y - g.y, nz = p.z - g.z;
+    V3 on;
+    const float n_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
+    const float n_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
+    const uint32_t r_guard = div_den_ok(radius) ? f2u(0x1p76f) - f2u(0x1p-103f) : 0u;
+    const bool n_odd = f2u(n_lo) - f2u(0x1p-103f) >= r_guard || f2u(n_hi) - f2u(0x1p-103f) >= r_guard;
+    const float yr = rcp_newton(radius);
+    on = mk(div_core(nx, radius, yr), div_core(ny, radius, yr), div_core(nz, radius, yr));
+    if (__builtin_expect(pt_ballot(n_odd) != 0ull, 0)) { // (rare)
+      if (n_odd) on = mk(nx / radius, ny / radius, nz / radius);
+    }
+    bool front = dot3(d, on) < 0.0f; // :137
+    V3 n = front ? on : mk(-on.x, -on.y, -on.z);
+    V3 alb = mk(m0.x, m0.y, m0.z);
+
+    if (mtype == 0 || mtype == 1) {
+      V3 rs = random_in_unit_sphere(seed); // both DIFFUSE (:217) and METAL (:240) draw one
+      V3 nd;
+      bool ok = true;
+      if (mtype == 0) { // DIFFUSE :212-229
+        V3 ruv = normalize3(rs);
+        nd = mk(n.x + ruv.x, n.y + ruv.y, n.z + ruv.z);
+      } else { // METAL :232-247
+        V3 refl = reflect3(d, n);
+        float fuzz = m0.w;
+        nd = mk(fma_(fuzz, rs.x, refl.x), fma_(fuzz, rs.y, refl.y), fma_(fuzz, rs.z, refl.z));
+        ok = dot3(n, nd) > 0.0f;
+      }
+      if (ok) {
+        o = p; d = nd;
+        col.x *= alb.x; col.y *= alb.y; col.z *= alb.z;
+      } else {
+        finished = true; // absorbed: return vec3(0.) :327-329
+      }
+    } else if (mtype == 2) { // GLASS :250-282
+      float ri = m1.x;
+      float ratio = front ? (1.0f / ri) : ri;
+      float inv = inv_sqrt_rn(a);
+      V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
+      float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
+      float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
+      float sin_theta = sqrt_rn(fma_(-cos_theta, cos_theta, 1.0f));
+      bool cannot_refract = ratio * sin_theta > 1.0f;
+      float refl_amount = reflectance(cos_theta, ratio);
+      float rnd = hash1(seed);
+      V3 nd;
+      if (cannot_refract || refl_amount > rnd) {
+        nd = reflect3(ud, n);
+      } else { // GLSL refract
+        float dni = dot3(n, ud);
+        float k = fma_(-(ratio * ratio), fma_(-dni, dni, 1.0f), 1.0f);
+        if (k < 0.0f) {
+          nd = mk(0.f, 0.f, 0.f);
+        } else {
+          float t = fma_(ratio, dni, sqrt_rn(k));
+          nd = mk(fma_(-t, n.x, ratio * ud.x), fma_(-t, n.y, ratio * ud.y),
+                  fma_(-t, n.z, ratio * ud.z));
+        }
+      }
+      o = p; d = nd;
+      col.x *= alb.x; col.y *= alb.y; col.z *= alb.z;
+    } else if (mtype == 3) { // EMISSIVE (extension): radiance = throughput * emission
+      sum.x += col.x * alb.x; sum.y += col.y * alb.y; sum.z += col.z * alb.z;
+      finished = true;
+    } else {
+      finished = true; // unrecognised material absorbs, :284-285
+    }
+
+    if (!finished) {
+      a = dot3(d, d);
+      depth++;
+      if (depth >= A.max_depth) { // loop bound :300 exhausted -> return color :338
+        sum.x += col.x; sum.y += col.y; sum.z += col.z;
+        finished = true;
+      }
+    }
+  }
+
+  if (finished) {
+    sample++;
+    if (sample >= A.spp) {
+      float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
+      reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
+      if (item_tile != 0xffffffffu) atomicMax(&A.tile_cost[item_tile], item_segs);
+      alive = false;
+    } else {
+      new_path = true;
+    }
+  }
+}
+
+} // namespace ptk

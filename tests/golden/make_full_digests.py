@@ -31,6 +31,15 @@ t, a = render_scene(sc)
 out["config2_1920x1080_64x16spp_decorrelated"] = {
     "sha256": hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest(),
     "segments": int(t.stats().segments)}
+t.close()
+# BASELINE config 3 as bench.py --config 3 renders it: 3840x2160, 4096 spp = 256 passes of 16 spp with
+# decorrelated pass times, 64 passes per launch (pass-order accumulation: any launch grouping gives the same bits)
+sc = scenes.config3(3840, 2160, 16, 256, 50)
+sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+t, a = render_scene(sc, passes_per_launch=64)
+out["config3_3840x2160_256x16spp_decorrelated"] = {
+    "sha256": hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest(),
+    "segments": int(t.stats().segments)}
 path = os.path.join(HERE, "full_frame_digests.json")
 if os.environ.get("GRAFT_REPO_ROOT"):
     path = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "full_frame_digests.json")

@@ -20,8 +20,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ptrace.h")
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+DEV_HEADER = os.path.join(ROOT, "include", "ptrace_dev.h")
+
+
+def declared_symbols(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", text)))
 
@@ -35,6 +38,11 @@ def test_library_exports_every_declared_symbol(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", LIB_PATH], text=True)
     exported = set(re.findall(r" T (pt_[a-z0-9_]+)", out))
     assert set(syms) <= exported
+    # the developer diagnostics live in their own header (outside the versioned ABI); together the two
+    # headers declare EVERYTHING the library exports as pt_*
+    dev = declared_symbols(DEV_HEADER)
+    assert dev and set(dev) <= exported and not set(dev) & set(syms)
+    assert exported == set(syms) | set(dev), sorted(exported ^ (set(syms) | set(dev)))
     # nothing but the C ABI is exported as pt_*, and no oracle symbol leaked into the product
     assert not re.search(r"\bora_", out)
 

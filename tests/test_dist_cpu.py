@@ -108,3 +108,26 @@ def test_bench_starts_its_own_ranks():
 def test_bench_reports_a_failed_rank():
     rc, lines, err = _run_bench("--gpus", "2", "--spawn-selftest", "fail")
     assert rc != 0
+
+
+def test_bench_workload_plan_and_digest_helpers():
+    """The N-independent workload bench.py times by default (strong scaling): config 2 = 16 steps of
+    4 x 16 spp = 1024 spp, config 3 = 64 steps = 4096 spp, whatever the rank count; the frame
+    digest is the one tests/golden/make_full_digests.py records (sha256 of the fp32 bytes)."""
+    import hashlib
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.plan_steps(1024, 16, 4, None) == (16, 64)
+    assert bench.plan_steps(4096, 16, 4, None) == (64, 64)
+    assert bench.plan_steps(1024, 16, 4, 5) == (5, 64)
+    for key in ("2", "3"):
+        cfg = bench.BENCH_CONFIGS[key]
+        assert cfg["digest"] in bench.load_digests(), "no committed digest for --config %s" % key
+    a = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)
+    assert bench.frame_digest(a) == hashlib.sha256(a.tobytes()).hexdigest()
+    assert bench.frame_digest(torch.from_numpy(a)) == bench.frame_digest(a)
+    ap_default = [ln for ln in open(os.path.join(ROOT, "bench.py")) if '"--scaling"' in ln]
+    assert ap_default and 'default="strong"' in ap_default[0]

@@ -135,6 +135,42 @@ def test_random_scenes_bit_exact_through_the_grid(ora, seed):
     t.close()
 
 
+@pytest.mark.parametrize("seed,offset", [(0, (300.0, -40.0, 120.0)), (1, (-2.0e3, 15.0, 9.0e2)), (2, (4.0e3, 0.0, -4.0e3)),
+                                         (3, (1.0e5, 2.0e4, -3.0e5))])
+def test_translated_scenes_through_the_grid(ora, seed, offset):
+    """A field of small spheres and its camera, moved far from the origin.  The walk's slab and plane
+    times are fma(plane, 1/d, -(o * 1/d)) in ABSOLUTE coordinates, so their rounding grows with |c0|;
+    the registration inflation carries that term (pt_grid.hpp eps_dda: at the last offset delta_g is 25,
+    every sphere sits in hundreds of cells — or the scene gets no grid at all and the hierarchy serves
+    it).  Bit-exact either way."""
+    import ctypes as C
+
+    rng = np.random.default_rng(13000 + seed)
+    sc = random_scene(rng, 130, 96, 54, 3, 8, 2)
+    small = rng.random(130) < 0.9
+    sc.spheres["radius"][small] = (np.sign(sc.spheres["radius"][small]) * rng.uniform(0.05, 0.4, small.sum())).astype(np.float32)
+    sc.spheres["center"] *= np.float32(6.0)
+    off = np.asarray(offset, np.float64)
+    sc.spheres["center"] = (sc.spheres["center"].astype(np.float64) + off).astype(np.float32)
+    la = abi.PtLookAtIn()
+    la.width, la.height = 96, 54
+    la.look_from = abi.d3(*(off + rng.uniform(-10, 10, 3)))
+    la.look_at = abi.d3(*(off + rng.uniform(-2, 2, 3)))
+    la.vup = abi.d3(0, 1, 0)
+    la.vfov_radians = math.radians(50.0)
+    la.focus_distance = 10.0
+    la.aperture = 0.0
+    assert scenes._lib().pt_camera_look_at(C.byref(la), C.byref(sc.params)) == 0
+    t, got = render_scene(sc, geometry_path=abi.PT_GEOM_GRID)
+    ref, seg = ora.render(sc.spheres, sc.params, 2)
+    st = t.stats()
+    g, r = bits(got), bits(ref)
+    assert np.array_equal(g, r), "offset %s (path %d): %d of %d values differ" % (offset, st.geometry_path, (g != r).sum(), g.size)
+    assert st.segments == seg
+    assert st.geometry_path in (abi.PT_GEOM_GRID, abi.PT_GEOM_BVH), st.geometry_path
+    t.close()
+
+
 def test_the_grid_fuzz_did_run_through_the_grid():
     assert len(GRID_USED) == 48 and sum(GRID_USED) >= 36, GRID_USED
 

@@ -810,6 +810,32 @@ def test_grid_kernels_for_scenes_beyond_the_lds(ora):
 
 
 @pytest.mark.parametrize("path", [abi.PT_GEOM_BVH, abi.PT_GEOM_GRID])
+def test_measuring_twin_equals_the_timed_kernel(ora, path):
+    """bench.py's `roofline.executed` tallies come from a DIFFERENT binary than the one it times (the
+    `_count` twin of the walk kernel: same body + wave-uniform counters, different register
+    allocation).  The tallies only describe the timed kernel if the twin takes the same control
+    flow: same image bits, same segment count, on the bench's own scene (structure staged in LDS)."""
+    sc = scenes.config2(256, 144, 4, 3, 50)
+    t, got = render_scene(sc, geometry_path=path)
+    st = t.stats()
+    assert st.geometry_path == path and sum(st.work) == 0  # the timed kernel tallies nothing
+    t.reset()
+    t.set_count_work(True)
+    t.set_params(sc.params)
+    t.render_passes(3)
+    twin = t.accum()
+    sw = t.stats()
+    assert_bit_equal(twin, got, "measuring twin vs timed kernel")
+    assert sw.segments == st.segments
+    w = sw.work
+    assert w[6] > 0 and w[6] * 64 >= sw.segments  # wave steps x 64 lanes bound the shaded segments
+    assert w[1] <= 64 * w[0] and w[3] <= 64 * w[2] and w[5] <= 64 * w[4]
+    ref, seg = ora.render(sc.spheres, sc.params, 3, window=(100, 116, 60, 68))
+    assert_bit_equal(twin[60:68, 100:116], ref[60:68, 100:116], "twin vs oracle window")
+    t.close()
+
+
+@pytest.mark.parametrize("path", [abi.PT_GEOM_BVH, abi.PT_GEOM_GRID])
 def test_carrying_stragglers_is_scheduling_only(ora, path):
     """PT_OPT_CARRY_LANES decides when a wave stops waiting for its last walks (they continue in
     the next wave step beside the fresh ones); images and segment counts cannot depend on it."""

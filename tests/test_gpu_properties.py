@@ -170,27 +170,57 @@ def test_config2_full_resolution_whole_frame_vs_oracle(ora):
     t.close()
 
 
-def test_bench_two_ranks_on_one_device():
-    """bench.py's N > 1 path on hardware, as far as a one-GPU box allows: two self-started ranks
-    (gloo collectives, both on cuda:0) render their row bands through libptrace; the line must
-    carry both ranks, the weak-scaling step (N x the passes per step) and the fixed-frame leg,
-    and rank 0's gathered frame must have been assembled (bench.py asserts its shape)."""
+def _bench(*extra, timeout=900):
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
-                        "--width", "480", "--height", "270", "--steps", "2", "--warmup", "1", "--steps-per-launch", "2",
-                        "--no-cpu-baseline", "--no-list-walk", "--no-work-count"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(extra),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["scaling"] == "weak"
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py's N > 1 path on hardware, as far as a one-GPU box allows: two self-started ranks
+    (gloo collectives, both on cuda:0) render their row bands of BASELINE config 2 — the DEFAULT
+    workload: strong scaling, the fixed 1920x1080x1024-spp frame — through libptrace; rank 0's
+    gathered frame must hash to the committed single-GPU digest (the check an RCCL run makes
+    too), and the weak-scaling point must be reported beside it."""
+    d = _bench("--gpus", "2", "--backend", "gloo", "--same-device", "--warmup", "4",
+               "--no-cpu-baseline", "--no-list-walk", "--no-work-count")
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["scaling"] == "strong"
+    assert d["steps"] == 16 and d["converged_frame_spp"] == 1024 and "config2" in d["config"]["workload"]
     assert len(d["per_rank_render_kernel_ms"]) == 2 and min(d["per_rank_render_kernel_ms"]) > 0
+    assert d["config"]["passes_per_launch"] == 16 * 4  # steps per launch x passes per step, whatever N
+    gc = d["gather_check"]
+    assert gc and gc["key"] == "config2_1920x1080_64x16spp_decorrelated"
+    assert d["gather_matches_single_gpu"] is True and gc["segments_match"] is True, gc
+    ws = d["weak_series"]
+    assert ws and ws["scaling"] == "weak" and ws["spp"] == 2 * 1024 and ws["sec"] > 0
+    assert abs(d["sec_to_converged_frame"] - d["ms_per_step"] * 16 / 1e3) < 1e-3
+    assert d["value"] > 0 and d["segments"] > 0 and d["first_frame_ms"] > 0
+
+
+def test_bench_weak_scaling_and_small_frames():
+    """--scaling weak keeps the round-2 semantics (N x the passes per step on 1/N of the rows); a
+    workload that is not the committed one reports no digest verdict instead of a wrong one."""
+    d = _bench("--gpus", "2", "--backend", "gloo", "--same-device", "--scaling", "weak",
+               "--width", "480", "--height", "270", "--steps", "2", "--warmup", "1", "--steps-per-launch", "2",
+               "--no-cpu-baseline", "--no-list-walk", "--no-work-count", "--no-first-frame")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["passes_per_launch"] == 2 * 4 * 2  # steps per launch x passes per step x ranks
-    ff = d["fixed_frame"]
-    assert ff and ff["spp"] == 1024 and ff["scaling"] == "strong" and ff["sec"] > 0 and d["sec_to_converged_frame"] == ff["sec"]
+    assert d["gather_matches_single_gpu"] is None and d["weak_series"] is None
     assert d["value"] > 0 and d["segments"] > 0
+
+
+def test_bench_single_gpu_line_matches_the_committed_digest():
+    """N = 1, default flags (minus the slow legs): the frame bench.py times IS the committed frame."""
+    d = _bench("--no-cpu-baseline", "--no-list-walk", "--warmup", "4")
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["gather_matches_single_gpu"] is True
+    ex = d["roofline"]["executed"]
+    assert ex and ex["twin_segments_equal_timed_kernel"] is True
+    assert d["roofline"]["frac"] and 0 < d["roofline"]["frac"] <= 1

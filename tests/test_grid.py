@@ -41,7 +41,10 @@ def build(spheres):
     index = np.zeros(counts[5], np.uint32)
     rc = lib.pt_build_grid(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), vp(cells), cells.size, vp(entries),
                            entries.size, vp(index), index.size)
-    return rc, dict(n=counts[:3].astype(np.int64), n_cell_entries=int(counts[3]), n_always=int(counts[4]),
+    consts = np.zeros(10, np.float32)  # what pt_render_passes copies into the launch arguments
+    assert lib.pt_grid_walk_constants(ptr, n, vp(consts)) == 0
+    return rc, dict(r2_near=consts[0], lo_n=consts[1:4].copy(), hi_n=consts[4:7].copy(), inv_h=consts[7:10].copy(),
+                    n=counts[:3].astype(np.int64), n_cell_entries=int(counts[3]), n_always=int(counts[4]),
                     n_entries=int(counts[5]), max_entries=int(counts[6]), nonempty=int(counts[7]), lo=geom[0:3], h=geom[3:6],
                     hi=geom[6:9], c0=geom[9:12], s0=margin[0], rmin=margin[1], rmax=margin[2], d_near=margin[3],
                     delta_g=np.float32(dg.value), cells=cells, entries=entries, index=index)
@@ -55,6 +58,22 @@ GRID_SCENES = dict(SCENES)
 GRID_SCENES["mixed_radii"] = lambda: np.concatenate(
     [random_field(200, 11, extent=10.0, rmax=0.3, giants=1), random_field(6, 12, extent=8.0, rmax=4.0, giants=0)])
 GRID_SCENES["flat"] = lambda: _flat()
+# the same fields far from the origin: the walk's slab and plane times are evaluated in ABSOLUTE
+# coordinates (fma(plane, 1/d, -(o * 1/d))), so their rounding scales with |c0|, not with the scene
+GRID_SCENES["field300_far"] = lambda: _moved(SCENES["field300"](), (3.0e3, -1.5e3, 2.0e3))
+GRID_SCENES["flat_far"] = lambda: _moved(_flat(), (-2.5e3, 40.0, 1.0e3))
+GRID_SCENES["config2_far"] = lambda: _moved(SCENES["config2"](), (500.0, 0.0, -300.0), giants_too=True)
+
+
+def _moved(sph, by, giants_too=False):
+    """translate a scene (float32 arithmetic on the centres, like a host that builds it there)"""
+    s = sph.copy()
+    big = np.abs(s["radius"]) > 100.0
+    sel = np.ones(len(s), bool) if giants_too else ~big
+    s["center"][sel] = (s["center"][sel].astype(np.float64) + np.asarray(by)).astype(np.float32)
+    if not giants_too:  # keep far-out giants below the field
+        s["center"][big, 0] += np.float32(by[0]); s["center"][big, 2] += np.float32(by[2])
+    return s
 
 
 def _flat():
@@ -101,7 +120,7 @@ def test_structure(name):
     dk = np.sqrt(float(g["rmin"]) ** 2 + 40.0 * U * float(g["d_near"]) ** 2) - float(g["rmin"]) + 16.0 * U * float(g["rmax"])
     assert g["delta_g"] >= dk and g["delta_g"] >= delta_of(float(g["rmin"]), float(g["rmax"]), float(g["d_near"]))
     # ... and is not absurd next to a cell
-    assert g["delta_g"] < 0.6 * float(g["h"].min()) or name in ("clumps",)
+    assert g["delta_g"] < 0.6 * float(g["h"].min()) or name in ("clumps",) or name.endswith("_far")
     # registration: a sphere is an entry of EVERY cell its box inflated by delta_g touches
     lo, h, nn = g["lo"].astype(np.float64), g["h"].astype(np.float64), g["n"]
     member = {}
@@ -119,7 +138,7 @@ def test_structure(name):
     assert np.all(c[gridded] - r[gridded, None] - float(g["delta_g"]) >= lo - 1e-9)
     assert np.all(c[gridded] + r[gridded, None] + float(g["delta_g"]) <= g["hi"].astype(np.float64) + 1e-9)
     # cells of about one sphere each, a bounded number of copies
-    assert g["n_cell_entries"] <= 8 * len(gridded) + 64
+    assert g["n_cell_entries"] <= 8 * len(gridded) + 64 or name.endswith("_far")
 
 
 def test_giants_and_big_spheres_are_tested_for_every_ray():
@@ -129,6 +148,17 @@ def test_giants_and_big_spheres_are_tested_for_every_ray():
     assert sorted(always[always != PAD].tolist()) == [0, 481, 482, 483]  # the ground and the three r = 1 spheres
     assert g["n"][1] == 1 and g["n"][0] >= 16 and g["n"][2] >= 16             # one layer of cells over the flat field
     assert g["s0"] < 20.0
+
+
+def test_a_field_too_far_from_the_origin_for_fp32_planes_gets_no_grid():
+    """At |c0| = 3e5 a float32 coordinate resolves 0.03 — a sixth of config 2's sphere radius: the
+    registration inflation (which carries |c0| since round 3) would put every sphere into dozens of
+    cells, the builder gives up, and the scene runs through the hierarchy / the list instead."""
+    rc, g = build(_moved(SCENES["config2"](), (1.0e5, 0.0, -3.0e5), giants_too=True))
+    assert rc == abi.PT_ERR_NOT_READY
+    rc, near = build(SCENES["config2"]())
+    rc2, far = build(GRID_SCENES["config2_far"]())
+    assert rc == 0 and rc2 == 0 and far["delta_g"] > near["delta_g"]  # the |c0| term at work
 
 
 def test_scenes_without_a_grid():
@@ -205,8 +235,9 @@ def brute_force(o, d, sph):
 
 
 def walk(g, o, d, sph):
-    """pt_trace_kernel_grid's PHASE 1 (same formulas, fp32): returns closest, sphere index, and the
-    number of entries looked at per ray; far rays that enter the box take the literal loop"""
+    """pt_trace_kernel_grid's PHASE 1, formula for formula in fp32 (grid_walk, pt_grid_walk.hpp) with the
+    entry constants the launch really uses (pt_grid_walk_constants): returns closest, sphere index,
+    and the number of entries looked at per ray; far rays that enter the box take the literal loop"""
     n = len(o)
     ent, index = g["entries"], g["index"].astype(np.int64)
     closest = np.full(n, MAX_T, np.float32)
@@ -227,27 +258,38 @@ def walk(g, o, d, sph):
     allr = np.arange(n)
     for k in range(g["n_cell_entries"], g["n_entries"]):
         test_entries(allr, np.full(n, k))
+    # ---- the kernel's entry arithmetic, operation for operation (pt_grid_walk.hpp) -------------------
+    # (one liberty: 1/d is the correctly rounded quotient here, v_rcp_f32 — good to 1 ulp — in the
+    # kernel; the error budget of pt_grid.hpp counts the reciprocal as a rounded operand either way)
     with np.errstate(divide="ignore"):
         inv = np.clip(f32(1.0) / d, f32(-1e18), f32(1e18)).astype(np.float32)
     pos_dir = inv > 0
-    td = f32(g["h"][None, :] * np.abs(inv))
+    H = np.broadcast_to(g["h"][None, :], d.shape)
+    td = f32(H * np.abs(inv))
     p = f32(o - g["c0"][None, :])
-    D = f32(np.sqrt(fma(p[:, 2], p[:, 2], fma(p[:, 1], p[:, 1], f32(p[:, 0] * p[:, 0])))) + g["s0"])
-    near = D <= f32(g["d_near"] * np.float32(0.9999))
-    mm = fma(np.where(near, np.float32(1e-6), np.float32(1.7e-3)).astype(np.float32), D, f32(np.full(n, 1e-30)))
-    t1 = f32(f32(f32(g["lo"][None, :] - mm[:, None]) - o) * inv)
-    t2 = f32(f32(f32(g["hi"][None, :] + mm[:, None]) - o) * inv)
-    tn = np.maximum(np.minimum(t1, t2).max(1), np.float32(0))
-    tf = np.maximum(t1, t2).min(1)
+    r2 = fma(p[:, 2], p[:, 2], fma(p[:, 1], p[:, 1], f32(p[:, 0] * p[:, 0])))
+    near = r2 <= g["r2_near"]
+    mm = np.where(near, np.float32(0), f32(np.float32(1.7e-3) * f32(np.sqrt(r2) + g["s0"]))).astype(np.float32)
+    oi = f32(o * inv)                                              # oix = o.x * ix
+    lo_m = f32(g["lo_n"][None, :] - mm[:, None])                   # K.grid_lo_n - mm
+    hi_m = f32(g["hi_n"][None, :] + mm[:, None])
+    t1 = fma(lo_m, inv, -oi)                                       # fma(lo_n - mm, ix, -oix)
+    t2 = fma(hi_m, inv, -oi)
+    tn = np.maximum(np.maximum(np.minimum(t1[:, 0], t2[:, 0]), np.minimum(t1[:, 1], t2[:, 1])),
+                    np.maximum(np.minimum(t1[:, 2], t2[:, 2]), np.float32(0)))
+    tf = np.minimum(np.minimum(np.maximum(t1[:, 0], t2[:, 0]), np.maximum(t1[:, 1], t2[:, 1])), np.maximum(t1[:, 2], t2[:, 2]))
     enter = tn <= np.minimum(tf, closest)
     literal = enter & ~near
     active = enter & near
     nn = g["n"]
-    fcell = f32(f32(fma(d, np.broadcast_to(tn[:, None], d.shape), o) - g["lo"][None, :]) * f32(1.0 / g["h"].astype(np.float64))[None, :])
+    LO = np.broadcast_to(g["lo"][None, :], d.shape)
+    # the cell that holds the entry point: (fma(d, tn, o) - lo) * inv_h, floor, clamp
+    fcell = f32(f32(fma(d, np.broadcast_to(tn[:, None], d.shape), o) - LO) * g["inv_h"][None, :])
     fcell = np.where(active[:, None], fcell, np.float32(0))  # rays that do not walk: anything finite
     cell3 = np.clip(np.floor(fcell).astype(np.int64), 0, nn[None, :] - 1)
-    bnd = fma(f32(cell3 + pos_dir), np.broadcast_to(g["h"][None, :], d.shape), np.broadcast_to(g["lo"][None, :], d.shape))
-    tm = np.maximum(f32(f32(bnd - o) * inv), tn[:, None])
+    # far planes of that cell and their crossing times, never before the entry time: fma(b, ix, -oix)
+    bnd = fma(f32(cell3 + pos_dir), H, LO)
+    tm = np.maximum(fma(bnd, inv, -oi), tn[:, None])
     rem = np.where(pos_dir, nn[None, :] - 1 - cell3, cell3) + 1
     first, count = (g["cells"] & 0xFFFFFF).astype(np.int64), (g["cells"] >> 24).astype(np.int64)
     for _ in range(int(nn.sum()) + 4):
@@ -275,7 +317,8 @@ def walk(g, o, d, sph):
     return closest, hit, looked, literal
 
 
-@pytest.mark.parametrize("name", ["config2", "field300", "clumps", "field17_no_giant", "config5", "mixed_radii", "flat"])
+@pytest.mark.parametrize("name", ["config2", "field300", "clumps", "field17_no_giant", "config5", "mixed_radii", "flat",
+                                  "field300_far", "flat_far", "config2_far"])
 def test_walk_returns_the_pair_hit_world_returns(name):
     sph = GRID_SCENES[name]()
     rc, g = build(sph)

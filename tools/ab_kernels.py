@@ -1,0 +1,76 @@
+"""Dev tool: A/B of two builds of libptrace.so on ONE device (devices differ by up to ~10 %, and so do
+the boxes of two gpurun calls — never compare across calls).
+
+    python tools/ab_kernels.py libA.so libB.so [rounds]      driver: alternates A B A B ..., one child process per run
+    PT_LIB=lib.so python tools/ab_kernels.py --child          one run: forced-path launches of the BASELINE configs
+
+Prints per (config, path) the kernel time of the library's HIP events (min over the repetitions)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child():
+    from ray_tracer_webgl_amd import abi, scenes
+    from ray_tracer_webgl_amd.tracer import PathTracer
+
+    sel = os.environ.get("AB_CASES", "").split(",") if os.environ.get("AB_CASES") else None
+    cases = [("c2grid", scenes.config2(1920, 1080, 16, 64, 50), 64, abi.PT_GEOM_GRID, 3),
+             ("c2bvh", scenes.config2(1920, 1080, 16, 64, 50), 64, abi.PT_GEOM_BVH, 2),
+             ("c2scalar", scenes.config2(1920, 1080, 16, 16, 50), 16, abi.PT_GEOM_SCALAR, 2),
+             ("c2band8", scenes.config2(1920, 1080, 16, 8, 50), 8, abi.PT_GEOM_GRID, 3),
+             ("c4scalar", scenes.config4(1024, 1024, 64, 8, 50), 8, abi.PT_GEOM_SCALAR, 2),
+             ("c4lds", scenes.config4(1024, 1024, 64, 8, 50), 8, abi.PT_GEOM_LDS, 2),
+             ("c5grid", scenes.config5(1920, 1080, 64, 4, 50), 4, abi.PT_GEOM_GRID, 3),
+             ("default", scenes.default_scene(1280, 702, 25, 8, 16), 16, abi.PT_GEOM_SCALAR, 3),
+             ("default1", scenes.default_scene(1280, 702, 1, 8, 1), 1, abi.PT_GEOM_SCALAR, 5)]
+    for name, sc, n, path, reps in cases:
+        if sel and name not in sel:
+            continue
+        sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+        pt = PathTracer(sc.params.width, sc.params.height)
+        pt.set_geometry_path(path)
+        pt.set_spheres(sc.spheres)
+        pt.set_params(sc.params)
+        pt.reserve_passes(n)
+        ms = []
+        for rep in range(reps + 1):  # the first launch settles the tile order
+            pt.reset()
+            pt.render_passes(n)
+            ms.append(pt.stats().render_kernel_ms)
+        print("%s %.4f %d" % (name, min(ms[1:]), pt.stats().segments), flush=True)
+        pt.close()
+
+
+def main():
+    libs = [os.path.abspath(x) for x in sys.argv[1:3]]
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    res = {}
+    for r in range(rounds):
+        for lib in libs:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, PT_LIB=lib),
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            if out.returncode != 0:
+                print("child failed for", lib, out.stderr[-1500:])
+                return 1
+            for line in out.stdout.splitlines():
+                k, ms, seg = line.split()
+                res.setdefault(k, {}).setdefault(lib, []).append((float(ms), int(seg)))
+    print("%-10s %s" % ("case", "  ".join("%26s" % os.path.basename(x) for x in libs)) + "   B/A")
+    for k, v in res.items():
+        a = min(x[0] for x in v[libs[0]])
+        b = min(x[0] for x in v[libs[1]])
+        segs = {x[1] for lib in libs for x in v[lib]}
+        print("%-10s %26s  %26s   %.4f%s" % (k, " ".join("%.3f" % x[0] for x in v[libs[0]]), " ".join("%.3f" % x[0] for x in v[libs[1]]),
+                                             b / a, "" if len(segs) == 1 else "  !! segment counts differ: %s" % segs))
+    return 0
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        child()
+    else:
+        raise SystemExit(main())
