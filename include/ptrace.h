@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 /* ---- error codes (returned by every int function; 0 = success) ------------------------------ */
 enum {
@@ -70,6 +70,11 @@ enum {
   PT_GEOM_SCALAR = 2,
   PT_GEOM_BVH = 3,
   PT_GEOM_GRID = 4,
+  PT_GEOM_SMALL = 5, /* lists of at most 16 spheres (the reference's `uniform Sphere[15] u_sphere_list`,
+                        static/shader.frag:103): no LDS copy, no candidate queue — four spheres per
+                        s_load_dwordx16 reach the VALU as SGPR operands, candidates are finished group by
+                        group in list order with the shader's own sequential acceptance.  A longer list
+                        falls back to SCALAR.  PT_GEOM_AUTO tries it first on such scenes. */
 };
 enum {
   PT_OPT_GEOMETRY_PATH = 1,
@@ -256,14 +261,39 @@ int pt_read_accum(pt_ctx* ctx, float* dst, size_t bytes);
 int pt_load_accum(pt_ctx* ctx, const float* src, size_t bytes);
 /* Render into caller-owned device memory (e.g. a torch tensor) instead; NULL restores. */
 int pt_bind_accum(pt_ctx* ctx, void* dev_ptr, size_t bytes);
-/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream.  The
+ * device's default stream IS the NULL handle: name it as hipStreamLegacy, PT_STREAM_LEGACY. */
 int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+#define PT_STREAM_LEGACY ((void*)1) /* = hipStreamLegacy */
 
 /* ---- temporal blend of the reference, static/shader.frag:387-404 + src/webgl.rs:186-204 --------
  * Blends the current resolved, gamma-encoded frame with `prev_rgba8` (the ping-pong texture)
  * using params.render_count / should_average / last_frame_weight, writes RGBA8 to `out_rgba8`.
  * Both are device or host pointers to local_rows*width*4 bytes. */
 int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
+
+/* ---- the reference's FRAME on device-resident textures: webgl::render (src/webgl.rs:180-205) ------
+ * The context owns the two RGBA8 ping-pong textures of src/webgl.rs:82-123 (local_rows*width texels
+ * each, cleared to 0: alpha 0 = "no data", static/shader.frag:391) and a canvas, all in HBM.
+ * pt_render_frame is ONE animation tick of src/lib.rs:92-102 with the current uniforms: trace one
+ * pass (samples_per_pixel samples at u_time = time + float(first_pass) * time_step), blend it with
+ * texture[(even_odd_count + 1) % 2] by the shader's render() rule using params.render_count /
+ * should_average / last_frame_weight, draw the result to the canvas and, when should_average, to
+ * texture[even_odd_count % 2].  Asynchronous on the context's stream; nothing crosses PCIe.
+ * pt_render_frames replays n_frames ticks at a constant frame interval from ONE captured hipGraph
+ * (trace + blend + advance; re-captured only when uniforms or scene changed), with the per-frame
+ * state of State::update_render_globals (src/state.rs:443-450) kept on the device: frame k of the
+ * call renders at u_time = time + float(first_pass + k) * time_step with
+ * render_count = min(params.render_count + k, max_render_count) and even_odd_count + k — the bits
+ * of n_frames pt_render_frame calls made with those uniforms.  The accumulation buffer of
+ * pt_render / pt_resolve is not involved.  pt_read_canvas / pt_read_texture copy RGBA8 texels out
+ * (host or device pointer; they synchronise), pt_write_texture copies a texture in. */
+int pt_clear_textures(pt_ctx* ctx);
+int pt_render_frame(pt_ctx* ctx, uint32_t even_odd_count);
+int pt_render_frames(pt_ctx* ctx, uint32_t even_odd_count, uint32_t max_render_count, uint32_t n_frames);
+int pt_read_canvas(pt_ctx* ctx, uint8_t* rgba_out);
+int pt_read_texture(pt_ctx* ctx, int index, uint8_t* rgba_out);
+int pt_write_texture(pt_ctx* ctx, int index, const uint8_t* rgba_in);
 
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 int pt_get_stats(pt_ctx* ctx, PtStats* out);

@@ -36,6 +36,12 @@ SIGNATURES = {
     "pt_load_accum": (C.c_int, [_ctx, _vp, C.c_size_t]),
     "pt_set_stream": (C.c_int, [_ctx, _vp]),
     "pt_blend_rgba8": (C.c_int, [_ctx, _vp, _vp]),
+    "pt_clear_textures": (C.c_int, [_ctx]),
+    "pt_render_frame": (C.c_int, [_ctx, C.c_uint32]),
+    "pt_render_frames": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_read_canvas": (C.c_int, [_ctx, _vp]),
+    "pt_read_texture": (C.c_int, [_ctx, C.c_int, _vp]),
+    "pt_write_texture": (C.c_int, [_ctx, C.c_int, _vp]),
     "pt_get_stats": (C.c_int, [_ctx, C.POINTER(abi.PtStats)]),
     "pt_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "pt_tune": (C.c_int, [_ctx, C.c_uint32]),

@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-PT_ABI_VERSION = 3
+PT_ABI_VERSION = 4
 
 PT_OK = 0
 PT_ERR_INVALID = -1
@@ -28,10 +28,11 @@ PT_EMISSIVE = 3
 PT_BG_SKY = 0
 PT_BG_BLACK = 1
 
-PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH, PT_GEOM_GRID = 0, 1, 2, 3, 4
+PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH, PT_GEOM_GRID, PT_GEOM_SMALL = 0, 1, 2, 3, 4, 5
 PT_OPT_GEOMETRY_PATH, PT_OPT_COUNT_WORK, PT_OPT_CARRY_LANES, PT_OPT_REFILL_MIN = 1, 2, 3, 4
 PT_TIME_STEP_DECORRELATED = 0.3618034  # include/ptrace.h
-GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh", 4: "grid"}
+PT_STREAM_LEGACY = 1  # include/ptrace.h: hipStreamLegacy, the default (NULL) stream by name
+GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh", 4: "grid", 5: "small"}
 
 f3 = C.c_float * 3
 d3 = C.c_double * 3

@@ -5,11 +5,15 @@ run_setters -> render -> (save).  Two display modes:
   * "reference": every frame is one fresh pass at u_time = `now`, blended with the previous
     RGBA8 frame by the shader's render() rule (static/shader.frag:387-404) into ping-pong
     textures (src/webgl.rs:186-204) — the reference's on-screen behaviour, 8-bit quantisation
-    and gamma-space averaging included.
+    and gamma-space averaging included.  The textures live on the device (pt_render_frame); a run
+    of ticks at a constant frame interval is replayed from one hipGraph (`frames`,
+    pt_render_frames) with the per-frame state counted on the device.
   * "linear": passes accumulate as fp32 linear radiance (north_star's "accumulated radiance")
     and are resolved at read-out; a camera change (render_count reset to 0,
     src/state.rs:343-346) clears the accumulation.
 """
+import time
+
 import numpy as np
 
 from .state import State
@@ -23,15 +27,26 @@ class FrameLoop:
         self.state = State(width, height)
         self.tracer = PathTracer(width, height, device=device)
         self.tracer.set_spheres(self.state.spheres())  # set_geometry, once (src/lib.rs:57)
-        # two RGBA8 textures cleared to 0 (alpha 0 = "no data", shader.frag:391)
-        self.textures = [np.zeros((height, width, 4), np.uint8), np.zeros((height, width, 4), np.uint8)]
-        self.canvas = None
+        # two RGBA8 textures cleared to 0 (alpha 0 = "no data", shader.frag:391): in HBM, owned by the context
+        self.tracer.clear_textures()
+        self._canvas = None
         self.prev_now = 0.0
         self.frames_rendered = 0
 
     def close(self):
         self.tracer.close()
         self.state.close()
+
+    @property
+    def canvas(self):
+        """The last frame drawn, RGBA8 (read back from the device on demand)."""
+        if self.mode == "reference":
+            return self.tracer.read_canvas()
+        return self._canvas
+
+    @property
+    def textures(self):
+        return [self.tracer.read_texture(0), self.tracer.read_texture(1)]
 
     def frame(self, now_ms, should_save=False):
         """One rAF tick.  Returns True when a frame was rendered."""
@@ -45,19 +60,127 @@ class FrameLoop:
         v = st.view()
         p = st.to_params(now_ms)                    # uniforms.run_setters, :96
         if self.mode == "reference":
-            self.tracer.reset()
             self.tracer.set_params(p)
-            self.tracer.render()
-            prev = self.textures[(v.even_odd_count + 1) % 2]   # src/webgl.rs:186-190
-            out = self.tracer.blend_rgba8(prev)                # draw to canvas :193-194
-            self.canvas = out
-            if v.should_average:                               # draw to the FBO :197-204
-                self.textures[v.even_odd_count % 2] = out
+            # webgl::render: previous frame = textures[(even_odd + 1) % 2] (src/webgl.rs:186-190), draw
+            # to the canvas (:193-194) and, when averaging, to the other texture (:197-204)
+            self.tracer.render_frame(v.even_odd_count)
         else:
             if v.render_count <= 1:  # accumulation restarts after any camera change
                 self.tracer.reset()
             self.tracer.set_params(p)
             self.tracer.render()
-            self.canvas = self.tracer.resolve_rgba8(True)
+            self._canvas = self.tracer.resolve_rgba8(True)
         self.frames_rendered += 1
         return True
+
+    def frames(self, n, first_now_ms, interval_ms):
+        """n rAF ticks at a constant frame interval with nothing else happening in between (no input:
+        update_position changes nothing, should_render stays true while unpaused) — one
+        pt_render_frames call: the first tick's uniforms go up once, the graph of one frame is
+        replayed n times, u_time / render_count / even-odd advance on the device exactly as
+        n calls of frame(first_now_ms + k * interval_ms) would advance them.  Reference mode only."""
+        assert self.mode == "reference" and n >= 1
+        st = self.state
+        assert not st.view().is_paused, "a paused State renders one frame per camera change, not a series"
+        st.update_position(first_now_ms - self.prev_now)
+        if not st.should_render(False):
+            return 0
+        st.update_render_globals()
+        v = st.view()
+        p = st.to_params(first_now_ms)
+        p.time_step = float(interval_ms)  # frame k: u_time = time + float(k) * interval (fp32, like the kernel's pass time)
+        p.first_pass = 0
+        self.tracer.set_params(p)
+        self.tracer.render_frames(v.even_odd_count, v.max_render_count, n)
+        for _ in range(n - 1):                       # the host's copy of the counters follows
+            st.update_render_globals()
+        self.prev_now = first_now_ms + (n - 1) * interval_ms
+        self.frames_rendered += n
+        return n
+
+
+def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device=0):
+    """bench.py --config default: the reference at its own operating point (State::default, 9 spheres,
+    1280x702 = images/14.png, depth 8; src/state.rs:127-135).  Times (i) the animation loop — 1 spp per
+    tick, blended into the RGBA8 textures, replayed from a hipGraph — and (ii) the 25-spp frames the
+    reference draws while paused (src/webgl.rs:342-346), plus (iii) the same ticks issued one by one
+    from the host (uniform upload + three launches per frame) for comparison.  Returns the JSON dict."""
+    from . import abi
+
+    out = {}
+    loop = FrameLoop(width, height, device=device, mode="reference")
+    st = loop.state
+    n_sph = st.view().n_spheres
+
+    def run(kind, n):
+        """kind: "graph" = the animation loop replayed from one hipGraph; "host" = the same ticks issued one
+        by one; "paused" = what the reference draws while paused: ONE 25-spp frame after every camera
+        change (render_count == 0, src/lib.rs:77-82, src/webgl.rs:342-346) — here after a yaw nudge"""
+        paused = kind == "paused"
+        st.set_flags(is_paused=paused)
+        loop.tracer.clear_textures()
+        now0, dt = 3000.0, 16.7
+
+        def ticks(k0, count):
+            if kind == "graph":
+                assert loop.frames(count, now0 + dt * k0, dt) == count
+            else:
+                for k in range(k0, k0 + count):
+                    if paused:
+                        st.set_camera_angles(-90.0 + 0.25 * (1 + (k & 1)), 0.0)  # a camera change: render_count = 0
+                    assert loop.frame(now0 + dt * k)
+
+        ticks(0, max(1, warmup))  # first capture, tile order, clocks
+        loop.tracer.synchronize()
+        loop.tracer.reset()
+        t0 = time.perf_counter()
+        ticks(1000, n)
+        loop.tracer.synchronize()
+        t1 = time.perf_counter()
+        s = loop.tracer.stats()
+        spp = st.to_params(0.0).samples_per_pixel
+        return {
+            "frames": n, "spp_per_frame": int(spp),
+            "ms_per_frame": round((t1 - t0) / n * 1e3, 4),
+            "frames_per_s": round(n / (t1 - t0), 1),
+            "mray_s": round(s.segments / (t1 - t0) / 1e6, 1),
+            "segments_per_frame": round(s.segments / n, 1),
+            "device_ms_per_frame": round(s.render_kernel_ms / n, 4) if kind == "graph" else None,
+            "geometry_path": abi.GEOM_NAMES.get(s.geometry_path, "?"),
+            "how": {"graph": "one hipGraph (trace + blend + advance) replayed %d times, per-frame state on the device" % n,
+                    "host": "uniform upload + trace + blend issued per frame from the host",
+                    "paused": "one frame per camera change, issued from the host (uniform upload + trace + blend)"}[kind],
+        }
+
+    anim = run("graph", n_frames)
+    anim_host = run("host", min(n_frames, 200))
+    paused = run("paused", max(8, n_frames // 8))
+    st.set_flags(is_paused=False)
+    canvas = loop.canvas
+    loop.close()
+    out = {
+        "metric": "frames/s of the reference's animation loop (1 spp per tick, temporal blend) at %dx%d" % (width, height),
+        "value": anim["frames_per_s"],
+        "unit": "frames/s",
+        "n_gpus": 1,
+        "steps": n_frames,
+        "warmup": warmup,
+        "ms_per_step": anim["ms_per_frame"],
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "State::default (%d spheres; the shader holds at most 15, static/shader.frag:103), %dx%d, depth 8, "
+                        "1 spp per frame blended into RGBA8 ping-pong textures (src/state.rs:127-135, src/lib.rs:65-104, "
+                        "src/webgl.rs:180-205)" % (n_sph, width, height),
+            "step": "one animation frame",
+        },
+        "reference_claim": "\"less than a second\" for a decent render (README.md:6): the only performance statement the reference makes",
+        "animation": anim,
+        "animation_issued_per_frame_from_the_host": anim_host,
+        "paused_25spp": paused,
+        "canvas_mean_rgb": [round(float(x), 3) for x in canvas[..., :3].reshape(-1, 3).mean(0)],
+    }
+    return out

@@ -94,6 +94,17 @@ struct pt_ctx {
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
   size_t tile_cap = 0;
+  bool tile_order_valid = false;  // d_tile_order holds an order for the current tile count
+  // the reference's frame (pt_render_frame / pt_render_frames): two RGBA8 textures + canvas, the
+  // device-side frame counter ([0] frames replayed since the series began, [1] a cell that stays 0)
+  uint32_t* d_tex[2] = {nullptr, nullptr};
+  uint32_t* d_canvas = nullptr;
+  size_t tex_pixels = 0;
+  uint32_t* d_frame_ctr = nullptr;
+  hipGraphExec_t frame_exec = nullptr;   // one frame (trace + blend + advance), captured once per uniform set
+  uint64_t epoch = 0;                    // bumped by everything a captured frame bakes in
+  uint64_t frame_exec_epoch = ~0ull;
+  uint32_t frame_exec_even_odd = 0, frame_exec_max_rc = 0;
   // counters + timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool
@@ -163,6 +174,20 @@ int ensure_buffers(pt_ctx* c) {
     PT_HIP(c, hipMalloc(&c->d_tile_order, tiles * sizeof(uint32_t)));
     PT_HIP(c, hipMemsetAsync(c->d_tile_cost, 0, tiles * sizeof(uint32_t), c->stream));
     c->tile_cap = tiles;
+    c->tile_order_valid = false;
+  }
+  if (c->tex_pixels < pix) {  // create_texture x2 (src/webgl.rs:82-123), cleared: alpha 0 = "no data" (shader.frag:391)
+    for (int k = 0; k < 2; k++) {
+      if (c->d_tex[k]) PT_HIP(c, hipFree(c->d_tex[k]));
+      c->d_tex[k] = nullptr;
+      PT_HIP(c, hipMalloc(&c->d_tex[k], pix * sizeof(uint32_t)));
+      PT_HIP(c, hipMemsetAsync(c->d_tex[k], 0, pix * sizeof(uint32_t), c->stream));
+    }
+    if (c->d_canvas) PT_HIP(c, hipFree(c->d_canvas));
+    c->d_canvas = nullptr;
+    PT_HIP(c, hipMalloc(&c->d_canvas, pix * sizeof(uint32_t)));
+    PT_HIP(c, hipMemsetAsync(c->d_canvas, 0, pix * sizeof(uint32_t), c->stream));
+    c->tex_pixels = pix;
   }
   if (c->resolve_pixels < pix) {
     if (c->d_resolve) PT_HIP(c, hipFree(c->d_resolve));
@@ -209,12 +234,13 @@ void list_paths(pt_ctx* c) {
   // on very short lists (measured: 484 spheres 4x, 10 001 spheres 14x slower than the grid), so
   // beyond 64 spheres PT_GEOM_AUTO does not spend launches on measuring them.
   const bool structured = c->have_bvh || c->have_grid;
+  if (c->n_spheres <= PT_MAX_SPHERES_SMALL) c->trial_paths[c->n_trials++] = PT_GEOM_SMALL;  // the reference's own scene size
   if (!structured || c->n_spheres <= 64u) {
-    if (c->n_spheres <= PT_MAX_SPHERES_LDS) c->trial_paths[c->n_trials++] = PT_GEOM_LDS;
-    c->trial_paths[c->n_trials++] = PT_GEOM_SCALAR;
+    if (c->n_spheres <= PT_MAX_SPHERES_LDS && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_LDS;
+    if (c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_SCALAR;
   }
-  if (c->have_bvh) c->trial_paths[c->n_trials++] = PT_GEOM_BVH;
-  if (c->have_grid) c->trial_paths[c->n_trials++] = PT_GEOM_GRID;
+  if (c->have_bvh && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_BVH;
+  if (c->have_grid && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_GRID;
 }
 
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
@@ -269,6 +295,9 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
     return bail(e, "hipMalloc(counters)");
   if ((e = hipMemsetAsync(c->d_counters, 0, PT_CTR_COUNT * sizeof(unsigned long long), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(counters)");
+  if ((e = hipMalloc(&c->d_frame_ctr, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(frame counter)");
+  if ((e = hipMemsetAsync(c->d_frame_ctr, 0, 2 * sizeof(uint32_t), c->stream)) != hipSuccess)
+    return bail(e, "hipMemsetAsync(frame counter)");
   // allow the trace kernel to use the CU's whole 160 KiB LDS for big sphere lists
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
@@ -313,6 +342,10 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_resolve) (void)hipFree(c->d_resolve);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->frame_exec) (void)hipGraphExecDestroy(c->frame_exec);
+  if (c->d_frame_ctr) (void)hipFree(c->d_frame_ctr);
+  for (int k = 0; k < 2; k++) if (c->d_tex[k]) (void)hipFree(c->d_tex[k]);
+  if (c->d_canvas) (void)hipFree(c->d_canvas);
   if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
   if (c->d_tile_order) (void)hipFree(c->d_tile_order);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -327,6 +360,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* hip_stream) {
   int rc = fold_events(c);
   if (rc != PT_OK) return rc;
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->epoch++;
   return PT_OK;
 }
 
@@ -465,6 +499,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     c->have_grid = true;
   }
   c->n_spheres = n;
+  c->epoch++;
   c->geom_tuned = 0;  // a new scene: PT_GEOM_AUTO measures again
   c->trial_state = 0;
   c->scene_regular = regular;
@@ -509,6 +544,7 @@ PT_API int pt_set_params(pt_ctx* c, const PtParams* p) {
   }
   c->params = *p;
   c->have_params = true;
+  c->epoch++;
   return PT_OK;
 }
 
@@ -518,6 +554,7 @@ PT_API int pt_resize(pt_ctx* c, uint32_t width, uint32_t height) {
   PT_HIP(c, hipStreamSynchronize(c->stream));
   c->width = width;
   c->height = height;
+  c->epoch++;
   c->have_params = false; // uniforms must be re-uploaded for the new size
   c->params.band_count = 0;
   c->local_rows = height;
@@ -533,6 +570,7 @@ PT_API int pt_reserve_passes(pt_ctx* c, uint32_t max_passes) {
   if (max_passes > c->reserved_passes) {
     PT_HIP(c, hipStreamSynchronize(c->stream));
     c->reserved_passes = max_passes;
+    c->epoch++;  // the slab may move
   }
   return ensure_buffers(c);
 }
@@ -626,19 +664,21 @@ PT_API int pt_load_accum(pt_ctx* c, const float* src, size_t bytes) {
   return PT_OK;
 }
 
-PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
-  if (!c) return PT_ERR_INVALID;
-  if (!c->have_spheres || !c->have_params)
-    return fail(c, PT_ERR_NOT_READY, "pt_render: pt_set_spheres and pt_set_params must come first");
-  if (n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_render_passes: n_passes == 0");
-  if (n_passes > c->reserved_passes)
-    return fail(c, PT_ERR_CAPACITY, "pt_render_passes: %u passes > %u reserved (pt_reserve_passes)",
-                n_passes, c->reserved_passes);
-  if (c->local_rows == 0) return PT_OK; // this band owns no rows
-  PT_HIP(c, hipSetDevice(c->device));
-
-  const PtParams& p = c->params;
+// Everything a trace-kernel launch needs, decided from the context's scene and uniforms: the
+// argument block, which kernel walks the sphere list, launch geometry.  No HIP call in here that
+// enqueues work, allocates or synchronises (capture-safe).
+struct Launch {
   PtKernelArgs A;
+  const void* kfn = nullptr;
+  uint32_t grid = 1, block = 256;
+  size_t lds = 0;
+  int path = 0;
+  int trial = -1;  // k when this launch is the autotune measurement of trial_paths[k]
+};
+
+static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L) {
+  const PtParams& p = c->params;
+  PtKernelArgs& A = L->A;
   memset(&A, 0, sizeof A);
   for (int k = 0; k < 3; k++) {
     A.origin[k] = p.camera_origin[k];
@@ -649,6 +689,14 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     A.cam_v[k] = p.v[k];
   }
   A.lens_radius = p.lens_radius;
+  {
+    bool off = p.lens_radius == 0.0f;
+    for (int k = 0; k < 3; k++) {
+      off = off && std::isfinite(p.u[k]) && std::isfinite(p.v[k]);
+      off = off && !(p.camera_origin[k] == 0.0f && std::signbit(p.camera_origin[k]));
+    }
+    A.lens_off = off ? 1u : 0u;
+  }
   A.time0 = p.time;
   A.time_step = p.time_step != 0.0f ? p.time_step : 1.0f;
   A.first_pass = p.first_pass;
@@ -685,7 +733,10 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   // which way PHASE 1 looks at the sphere list (bit-identical results whichever way)
   int path = c->geom_policy;
   int trial = -1; // k when this launch is the autotune measurement of trial_paths[k]
-  if (path == PT_GEOM_AUTO) {
+  if (path == PT_GEOM_AUTO && !allow_trials) {
+    try_finish_tuning(c);
+    path = c->geom_tuned ? c->geom_tuned : c->trial_paths[0];
+  } else if (path == PT_GEOM_AUTO) {
     try_finish_tuning(c);
     if (c->geom_tuned) path = c->geom_tuned;
     else if (c->trial_state == 0) { path = c->trial_paths[0]; c->trial_state = 1; } // cold launch: not measured
@@ -695,6 +746,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   // a forced path the scene cannot use falls back to the nearest one it can
   if (path == PT_GEOM_GRID && !c->have_grid) path = c->have_bvh ? PT_GEOM_BVH : PT_GEOM_SCALAR;
   if (path == PT_GEOM_BVH && !c->have_bvh) path = PT_GEOM_SCALAR;
+  if (path == PT_GEOM_SMALL && c->n_spheres > PT_MAX_SPHERES_SMALL) path = PT_GEOM_SCALAR;
   if (path == PT_GEOM_LDS && c->n_spheres > PT_MAX_SPHERES_LDS) path = PT_GEOM_SCALAR;
   c->geom_last = path;
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
@@ -803,11 +855,12 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     lds = scene + (size_t)PT_PARK_STRIDE * 4 * bvh_block;
   } else {
     // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
-    const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
+    const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS && path != PT_GEOM_SMALL;
     lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
-    kfn = path == PT_GEOM_LDS ? reinterpret_cast<const void*>(pt_trace_kernel)
-                              : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
-                                          : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
+    kfn = path == PT_GEOM_SMALL ? reinterpret_cast<const void*>(pt_trace_kernel_small)
+          : path == PT_GEOM_LDS ? reinterpret_cast<const void*>(pt_trace_kernel)
+                                : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
+                                            : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
   }
   uint32_t block = bvh_block ? bvh_block : (lds > 40 * 1024 ? 1024u : 256u);
   A.block_threads = block;
@@ -834,6 +887,47 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
   if (grid < 1) grid = 1;
+  // Launches of a few items per lane (the reference's 1-spp frame: two) cannot afford the shared
+  // queue: its head is ONE address, the reservations' atomics take their turn there (~25 ns each), and
+  // 28 000 of them are the frame's whole 0.78 ms.  Such launches deal reservations of one tile's 64
+  // items round-robin to the waves instead (no atomic; the cost-ordered tile list still spreads the
+  // heavy tiles over the waves).
+  A.n_waves = grid * (block / 64u);
+  A.queue_static = items < 8ull * (unsigned long long)A.n_waves * 64ull ? 1u : 0u;
+  if (A.queue_static) A.queue_chunk = 64u;
+
+  // cost feedback for the next launch's tile order: one atomicMax per item of pass 0.  A launch of one
+  // SHORT pass (the reference's 1-spp frame) would report from every item — the 64 lanes of a tile on
+  // one address — and stall its waves on the atomics (vmcnt completes in order): none there.
+  A.cost_feedback = (n_passes >= 2u || p.samples_per_pixel >= 8) ? 1u : 0u;
+  A.frame_ctr = c->d_frame_ctr + 1;  // the cell that stays 0 (pt_render_frames points at [0])
+  L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;
+  return PT_OK;
+}
+
+PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
+  if (!c) return PT_ERR_INVALID;
+  if (!c->have_spheres || !c->have_params)
+    return fail(c, PT_ERR_NOT_READY, "pt_render: pt_set_spheres and pt_set_params must come first");
+  if (n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_render_passes: n_passes == 0");
+  if (n_passes > c->reserved_passes)
+    return fail(c, PT_ERR_CAPACITY, "pt_render_passes: %u passes > %u reserved (pt_reserve_passes)",
+                n_passes, c->reserved_passes);
+  if (c->local_rows == 0) return PT_OK; // this band owns no rows
+  PT_HIP(c, hipSetDevice(c->device));
+
+  Launch L;
+  {
+    int rc = prepare_launch(c, n_passes, true, &L);
+    if (rc != PT_OK) return rc;
+  }
+  PtKernelArgs& A = L.A;
+  const PtParams& p = c->params;
+  const void* kfn = L.kfn;
+  const uint32_t grid = L.grid, block = L.block;
+  const size_t lds = L.lds;
+  const int path = L.path;
+  int trial = L.trial;
 
   // inside a stream capture (hipGraph) nothing may synchronise or allocate and timing events are
   // meaningless: the launch sequence itself is capture-safe, the measuring twins' set-up is not
@@ -872,10 +966,14 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   std::pair<hipEvent_t, hipEvent_t>* ev = capturing ? nullptr : &c->events[c->events_used++];
 
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
-  // queue order from the previous launch's per-tile cost (identity when there is none yet)
-  hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
-                     c->d_tile_order, A.tiles_x * A.tiles_y);
-  PT_HIP(c, hipGetLastError());
+  // queue order from the previous launch's per-tile cost (identity when there is none yet); launches
+  // that report no cost keep the order they find
+  if (A.cost_feedback || !c->tile_order_valid) {
+    hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
+                       c->d_tile_order, A.tiles_x * A.tiles_y);
+    PT_HIP(c, hipGetLastError());
+    c->tile_order_valid = true;
+  }
   if (capturing) trial = -1;
   if (trial >= 0) {
     for (int k = 0; k < 2; k++)
@@ -913,6 +1011,157 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
 }
 
 PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
+
+// ---- the reference's frame on device-resident textures ---------------------------------------------
+// webgl::render (src/webgl.rs:180-205) as the rAF closure calls it (src/lib.rs:92-102): one pass of the
+// hot path at the current uniforms, blended with the previous frame's texture by the shader's
+// render() rule (static/shader.frag:387-404), drawn to the canvas and — when averaging — to the
+// other texture.  Nothing crosses PCIe: the textures of src/webgl.rs:82-123 live in HBM.
+namespace {
+
+// enqueue one frame; ctr = the device cell holding this frame's number in its series
+int enqueue_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_render_count, bool advance) {
+  Launch L;
+  int rc = prepare_launch(c, 1, false, &L);
+  if (rc != PT_OK) return rc;
+  L.A.frame_ctr = ctr;
+  L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
+  L.A.wave_log = nullptr;
+  if (!c->tile_order_valid) {
+    hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost, c->d_tile_order,
+                       L.A.tiles_x * L.A.tiles_y);
+    PT_HIP(c, hipGetLastError());
+    c->tile_order_valid = true;
+  }
+  {
+    void* kargs[] = {&L.A};
+    PT_HIP(c, hipLaunchKernel(L.kfn, dim3(L.grid), dim3(L.block), kargs, L.lds, c->stream));
+  }
+  // the frame's one pass sits in the slab ({sum r, g, b, spp} per pixel): blend straight from there
+  const uint32_t n_pix = c->local_rows * c->width;
+  hipLaunchKernelGGL(pt_frame_blend_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream, c->d_slab, c->d_tex[0],
+                     c->d_tex[1], c->d_canvas, n_pix, ctr, c->params.render_count, even_odd0, max_render_count,
+                     c->params.should_average, c->params.last_frame_weight);
+  PT_HIP(c, hipGetLastError());
+  if (advance) {
+    hipLaunchKernelGGL(pt_frame_advance_kernel, dim3(1), dim3(64), 0, c->stream, c->d_frame_ctr, &c->d_counters[PT_CTR_HEAD]);
+    PT_HIP(c, hipGetLastError());
+  }
+  return PT_OK;
+}
+
+int frame_ready(pt_ctx* c, const char* who) {
+  if (!c) return PT_ERR_INVALID;
+  if (!c->have_spheres || !c->have_params)
+    return fail(c, PT_ERR_NOT_READY, "%s: pt_set_spheres and pt_set_params must come first", who);
+  if (c->count_work) return fail(c, PT_ERR_INVALID, "%s: not with PT_OPT_COUNT_WORK (the measuring twins are not frame kernels)", who);
+  return PT_OK;
+}
+
+} // namespace
+
+PT_API int pt_clear_textures(pt_ctx* c) {
+  if (!c) return PT_ERR_INVALID;
+  PT_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)c->local_rows * c->width * sizeof(uint32_t);
+  if (bytes == 0) return PT_OK;
+  for (int k = 0; k < 2; k++) PT_HIP(c, hipMemsetAsync(c->d_tex[k], 0, bytes, c->stream));
+  PT_HIP(c, hipMemsetAsync(c->d_canvas, 0, bytes, c->stream));
+  return PT_OK;
+}
+
+PT_API int pt_render_frame(pt_ctx* c, uint32_t even_odd_count) {
+  int rc = frame_ready(c, "pt_render_frame");
+  if (rc != PT_OK) return rc;
+  if (c->local_rows == 0) return PT_OK;
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  rc = enqueue_frame(c, c->d_frame_ctr + 1, even_odd_count, 0x7fffffff, false);  // frame 0 of a series of one
+  if (rc != PT_OK) return rc;
+  c->launches++;
+  c->samples += (uint64_t)c->local_rows * c->width * (uint64_t)c->params.samples_per_pixel;
+  return PT_OK;
+}
+
+PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_render_count, uint32_t n_frames) {
+  int rc = frame_ready(c, "pt_render_frames");
+  if (rc != PT_OK) return rc;
+  if (n_frames == 0 || c->local_rows == 0) return PT_OK;
+  if (max_render_count > 0x7fffffffu) max_render_count = 0x7fffffffu;
+  PT_HIP(c, hipSetDevice(c->device));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(c->stream, &cap);
+  if (cap != hipStreamCaptureStatusNone)
+    return fail(c, PT_ERR_INVALID, "pt_render_frames: the stream is being captured already (this call replays its own graph)");
+  // (re)capture ONE frame when the uniforms, the scene or anything else a launch bakes in has changed
+  if (!c->frame_exec || c->frame_exec_epoch != c->epoch || c->frame_exec_even_odd != even_odd_count ||
+      c->frame_exec_max_rc != max_render_count) {
+    if (c->frame_exec) { (void)hipGraphExecDestroy(c->frame_exec); c->frame_exec = nullptr; }
+    if (!c->tile_order_valid) {  // outside the capture: it runs once, not per frame
+      hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost, c->d_tile_order,
+                         ((c->width + 7) / 8) * ((c->local_rows + 7) / 8));
+      PT_HIP(c, hipGetLastError());
+      c->tile_order_valid = true;
+    }
+    hipGraph_t graph = nullptr;
+    PT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_frame(c, c->d_frame_ctr, even_odd_count, (int)max_render_count, true);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc != PT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&c->frame_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { c->frame_exec = nullptr; return fail(c, PT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    c->frame_exec_epoch = c->epoch;
+    c->frame_exec_even_odd = even_odd_count;
+    c->frame_exec_max_rc = max_render_count;
+  }
+  // the series starts at frame 0 with an empty queue; every replay leaves both ready for the next
+  PT_HIP(c, hipMemsetAsync(c->d_frame_ctr, 0, sizeof(uint32_t), c->stream));
+  PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  if (c->events_used == c->events.size()) {
+    if (c->events.size() >= 512) {
+      PT_HIP(c, hipStreamSynchronize(c->stream));
+      rc = fold_events(c);
+      if (rc != PT_OK) return rc;
+    } else {
+      hipEvent_t a, b;
+      PT_HIP(c, hipEventCreate(&a));
+      PT_HIP(c, hipEventCreate(&b));
+      c->events.emplace_back(a, b);
+    }
+  }
+  std::pair<hipEvent_t, hipEvent_t>& ev = c->events[c->events_used++];
+  PT_HIP(c, hipEventRecord(ev.first, c->stream));
+  for (uint32_t k = 0; k < n_frames; k++) PT_HIP(c, hipGraphLaunch(c->frame_exec, c->stream));
+  PT_HIP(c, hipEventRecord(ev.second, c->stream));
+  c->launches += n_frames;
+  c->samples += (uint64_t)n_frames * c->local_rows * c->width * (uint64_t)c->params.samples_per_pixel;
+  return PT_OK;
+}
+
+static int read_rgba8(pt_ctx* c, const uint32_t* src, uint8_t* out, const char* who) {
+  if (!c || !out) return fail(c, PT_ERR_INVALID, "%s: NULL argument", who);
+  PT_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)c->local_rows * c->width * 4;
+  if (bytes) PT_HIP(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDefault, c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+PT_API int pt_read_canvas(pt_ctx* c, uint8_t* rgba_out) { return read_rgba8(c, c ? c->d_canvas : nullptr, rgba_out, "pt_read_canvas"); }
+PT_API int pt_read_texture(pt_ctx* c, int index, uint8_t* rgba_out) {
+  if (c && (index < 0 || index > 1)) return fail(c, PT_ERR_INVALID, "pt_read_texture: index %d", index);
+  return read_rgba8(c, c ? c->d_tex[index] : nullptr, rgba_out, "pt_read_texture");
+}
+PT_API int pt_write_texture(pt_ctx* c, int index, const uint8_t* rgba_in) {
+  if (!c || !rgba_in) return fail(c, PT_ERR_INVALID, "pt_write_texture: NULL argument");
+  if (index < 0 || index > 1) return fail(c, PT_ERR_INVALID, "pt_write_texture: index %d", index);
+  PT_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)c->local_rows * c->width * 4;
+  if (bytes) PT_HIP(c, hipMemcpyAsync(c->d_tex[index], rgba_in, bytes, hipMemcpyDefault, c->stream));
+  PT_HIP(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
 
 
 // ---- include/ptrace_dev.h: developer diagnostics, not part of the versioned ABI ----------------
@@ -1023,9 +1272,10 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
 
 PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   if (!c) return PT_ERR_INVALID;
+  c->epoch++;
   if (key == PT_OPT_GEOMETRY_PATH) {
     if (value != PT_GEOM_AUTO && value != PT_GEOM_LDS && value != PT_GEOM_SCALAR && value != PT_GEOM_BVH &&
-        value != PT_GEOM_GRID)
+        value != PT_GEOM_GRID && value != PT_GEOM_SMALL)
       return fail(c, PT_ERR_INVALID, "pt_set_option: bad geometry path %d", value);
     c->geom_policy = value;
     return PT_OK;
@@ -1059,6 +1309,7 @@ PT_API int pt_tune(pt_ctx* c, uint32_t n_passes) {
   PT_HIP(c, hipSetDevice(c->device));
   PT_HIP(c, hipStreamSynchronize(c->stream));
   try_finish_tuning(c);
+  c->epoch++;
   return pt_reset_accum(c);
 }
 

@@ -34,11 +34,14 @@ namespace ptk {
 template <typename S, bool COUNT>
 __device__ __forceinline__ void bvh_walk(const PtKernelArgs& A, const Path& p, bool scan_lane, int n_live, Carry& cw,
                                          BvhWalk& w, Hit& h, Tally<COUNT>& tally) {
-  const V3& o = p.o; const V3& d = p.d; const float a = p.a;
-  float& closest = h.closest; int& hit = h.hit;
-  bool& carried = cw.carried; uint32_t& hit_pos = cw.hit_pos;
-  uint32_t& cur = w.cur; uint32_t& l0 = w.l0; uint32_t& l1 = w.l1; uint32_t& l2 = w.l2; uint32_t& l3 = w.l3; uint32_t& l_cnt = w.l_cnt;
-  uint32_t& q0 = w.q0; uint32_t& q1 = w.q1; uint32_t& q2 = w.q2; uint32_t& q3 = w.q3; uint32_t& q_cnt = w.q_cnt;
+  // the state is worked on in LOCAL copies and written back at the end: through the reference
+  // parameters it would be memory to every pass that runs before this function is inlined, and the
+  // loops below would be shaped (rotated, merged, made divergent) for memory operands instead of registers
+  const V3 o = p.o; const V3 d = p.d; const float a = p.a;
+  float closest = h.closest; int hit = h.hit;
+  bool carried = cw.carried; uint32_t hit_pos = cw.hit_pos;
+  uint32_t cur = w.cur, l0 = w.l0, l1 = w.l1, l2 = w.l2, l3 = w.l3, l_cnt = w.l_cnt;
+  uint32_t q0 = w.q0, q1 = w.q1, q2 = w.q2, q3 = w.q3, q_cnt = w.q_cnt;
   const uint32_t n_nodes = A.n_nodes;
   const bool fresh = scan_lane && !carried;
   const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
@@ -221,6 +224,10 @@ __device__ __forceinline__ void bvh_walk(const PtKernelArgs& A, const Path& p, b
   carried = cur < walk_end;
   tally.carried(carried);
   if (hit_pos != 0xffffffffu) hit = 0; // a hit; shading reads the slot's own copies (index not needed)
+  h.closest = closest; h.hit = hit;
+  cw.carried = carried; cw.hit_pos = hit_pos;
+  w.cur = cur; w.l0 = l0; w.l1 = l1; w.l2 = l2; w.l3 = l3; w.l_cnt = l_cnt;
+  w.q0 = q0; w.q1 = q1; w.q2 = q2; w.q3 = q3; w.q_cnt = q_cnt;
 }
 
 } // namespace ptk

@@ -25,11 +25,14 @@ template <typename S, bool COUNT>
 __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, bool scan_lane, int n_live, Carry& cw,
                                           GridWalk& w, Hit& h, Tally<COUNT>& tally) {
   karg_t& K = *kargs();
-  const V3& o = p.o; const V3& d = p.d; const float a = p.a;
-  float& closest = h.closest; int& hit = h.hit; uint32_t& lit_from = h.lit_from;
-  bool& carried = cw.carried; uint32_t& hit_pos = cw.hit_pos;
-  float& tmx = w.tmx; float& tmy = w.tmy; float& tmz = w.tmz; float& t_exit = w.t_exit;
-  uint32_t& cell = w.cell; uint32_t& rem = w.rem; uint32_t& pend = w.pend; bool& gactive = w.gactive;
+  // the state is worked on in LOCAL copies and written back at the end: through the reference
+  // parameters it would be memory to every pass that runs before this function is inlined, and the
+  // loops below would be shaped (rotated, merged, made divergent) for memory operands instead of registers
+  const V3 o = p.o; const V3 d = p.d; const float a = p.a;
+  float closest = h.closest; int hit = h.hit; uint32_t lit_from = h.lit_from;
+  bool carried = cw.carried; uint32_t hit_pos = cw.hit_pos;
+  float tmx = w.tmx, tmy = w.tmy, tmz = w.tmz, t_exit = w.t_exit;
+  uint32_t cell = w.cell, rem = w.rem, pend = w.pend; bool gactive = w.gactive;
   const uint32_t n_cell_entries = A.n_tree_slots;
   const bool fresh = scan_lane && !carried;
   const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
@@ -236,6 +239,10 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   carried = gactive || (pend >> 24) != 0u;
   tally.carried(carried);
   if (hit_pos != 0xffffffffu) hit = 0; // a hit; shading reads the slot's own copies (index not needed)
+  h.closest = closest; h.hit = hit; h.lit_from = lit_from;
+  cw.carried = carried; cw.hit_pos = hit_pos;
+  w.tmx = tmx; w.tmy = tmy; w.tmz = tmz; w.t_exit = t_exit;
+  w.cell = cell; w.rem = rem; w.pend = pend; w.gactive = gactive;
 }
 
 } // namespace ptk

@@ -82,6 +82,14 @@ struct PtKernelArgs {
   float fw, fh;                    // float(width), float(height)
   PtDiv div_per_tile, div_tiles_x, div_band_rows;  // by 64 * n_passes, tiles_x, band_rows
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
+  uint32_t lens_off;               // 1: lens_radius is 0, u and v are finite, no component of the origin is -0 (pt_refill.hpp start_sample)
+  uint32_t queue_static;           // 1: no queue atomics — wave w takes the reservations w, w + n_waves, w + 2 n_waves, ...
+                                   // (launches of a few items per lane: every reservation of the shared queue is an atomic
+                                   // on ONE address, ~25 ns each in turn; 28 000 of them ARE the 1-spp frame's 0.78 ms)
+  uint32_t n_waves;                // waves of the launch (grid x workgroup / 64)
+  uint32_t cost_feedback;          // 1: pass 0's items report their length (one atomicMax each) for the next launch's tile order
+  const uint32_t* frame_ctr;       // device cell added to the pass number in u_time (pt_render_frames: frames replayed from a
+                                   // hipGraph advance it on the device); points at a zero cell otherwise.  Never NULL.
 };
 
 enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_PHASES = 24, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
@@ -89,6 +97,7 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
 #define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
+#define PT_MAX_SPHERES_SMALL 16u   // PT_GEOM_SMALL: the whole list reaches the VALU from SGPRs, four spheres per s_load_dwordx16
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
 #define PT_PARK_DWORDS 14u  // per-lane path state parked in LDS during the hierarchy walk
 #define PT_PARK_STRIDE 15u  // dwords per lane in the parking area (odd: conflict-free columns)

@@ -101,6 +101,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       const bool scan_lane = p.alive && fast;
       if constexpr (S::BVH) bvh_walk<S, COUNT>(A, p, scan_lane, n_live, cw, bw, h, tally);
       else if constexpr (S::GRID) grid_walk<S, COUNT>(A, p, scan_lane, n_live, cw, gw, h, tally);
+      else if constexpr (S::SMALL) small_scan<S>(A, p, scan_lane, h);
       else list_scan<S>(A, p, scan_lane, h);
       literal_loop<S>(A, p, h);
     }
@@ -137,6 +138,12 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar(const 
 // lists beyond the LDS (10 232 < n <= 65 528): scalar-load walk, gathers from global memory
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(const PtKernelArgs A) {
   pt_trace_body<false, false>(A);
+}
+
+// lists of at most 16 spheres (PT_GEOM_SMALL: the reference's own scene size): no LDS, no candidate
+// queue, the list reaches the VALU group by group from SGPRs
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small(const PtKernelArgs A) {
+  pt_trace_body<false, false, 7>(A);
 }
 
 // The walk kernels are latency-bound, not issue-bound: for scenes small enough that LDS
@@ -316,6 +323,62 @@ extern "C" __global__ __launch_bounds__(256) void pt_blend_rgba8_kernel(
       for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
     }
     out[i] = o;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// The reference's FRAME on device-resident textures: webgl::render (src/webgl.rs:180-205) +
+// update_render_globals (src/state.rs:443-450) with the per-frame state on the device, so that a
+// frame can be replayed from a hipGraph without the host in the loop (pt_render_frames).
+// `slab` holds the frame's one pass ({sum r, g, b, spp} per pixel, straight from the trace kernel: no
+// accumulation buffer in between); ctr[0] = k, the number of frames drawn since the series began:
+//     render_count = min(render_count0 + k, max_render_count)     src/state.rs:449
+//     even_odd     = even_odd0 + k                                src/state.rs:448
+//     previous frame = texture[(even_odd + 1) % 2]                src/webgl.rs:186-190
+//     draw to the canvas; if should_average also to texture[even_odd % 2]   :193-204
+// The blend itself is static/shader.frag:387-404, operation for operation as pt_blend_rgba8_kernel.
+// --------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void pt_frame_blend_kernel(
+    const float4* slab, uint32_t* tex0, uint32_t* tex1, uint32_t* canvas, uint32_t n_pix, const uint32_t* ctr,
+    int render_count0, uint32_t even_odd0, int max_render_count, int should_average, float last_frame_weight) {
+  const uint32_t k = ctr[0];
+  const long long rc_ll = (long long)render_count0 + (long long)k;
+  const int render_count = rc_ll < (long long)max_render_count ? (int)rc_ll : max_render_count;
+  const uint32_t even_odd = even_odd0 + k;
+  const uint32_t* prev = ((even_odd + 1u) & 1u) ? tex1 : tex0;
+  uint32_t* out_tex = (even_odd & 1u) ? tex1 : tex0;
+  uint32_t stride = gridDim.x * blockDim.x;
+  float rc = (float)render_count;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    float4 v = slab[i];
+    const float scale = pixel_scale(v.w);
+    float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale),
+                   __builtin_sqrtf(v.z * scale)};
+    uint32_t pv = prev[i];
+    float pa = (float)(pv >> 24) / 255.0f;
+    uint32_t o = 255u << 24;
+    if (should_average && !(pa == 0.0f || render_count <= 1)) {
+      float total = rc + last_frame_weight;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
+        float merged = fma_(px[c], last_frame_weight, pr * rc) / total;
+        o |= unorm8(merged) << (8 * c);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
+    }
+    canvas[i] = o;
+    if (should_average) out_tex[i] = o;
+  }
+}
+
+// end of a frame: the next replay is frame k + 1, and its work queue starts at item 0
+extern "C" __global__ void pt_frame_advance_kernel(uint32_t* ctr, unsigned long long* queue_head) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctr[0] += 1u;
+    queue_head[0] = 0ull;
   }
 }
 

@@ -39,8 +39,9 @@ __device__ __forceinline__ bool regular_ray(const PtKernelArgs& A, const Path& p
 // launch's drain time.
 template <typename S>
 __device__ __forceinline__ void tail_mode(const PtKernelArgs& A, const Path& p, unsigned long long live, Hit& h) {
-  const V3& o = p.o; const V3& d = p.d; const float a = p.a;
-  float& closest = h.closest; int& hit = h.hit;
+  // (local copies, written back at the end: see pt_grid_walk.hpp)
+  const V3 o = p.o; const V3 d = p.d; const float a = p.a;
+  float closest = h.closest; int hit = h.hit;
   const uint32_t n_spheres = A.n_spheres;
   unsigned long long todo = live;
   const uint32_t last_entry = PT_LDS_ENTRIES(n_spheres) - 1u;
@@ -91,6 +92,7 @@ __device__ __forceinline__ void tail_mode(const PtKernelArgs& A, const Path& p, 
       hit = (int)(0xffffffffu - k_lo);
     }
   }
+  h.closest = closest; h.hit = hit;
 }
 
 // PHASE 1, scan.  Every sphere gets the cheap part of hit_sphere (:146-153: oc, half_b, c,
@@ -106,8 +108,8 @@ __device__ __forceinline__ void tail_mode(const PtKernelArgs& A, const Path& p, 
 // (lane, sphere) pair.
 template <typename S>
 __device__ __forceinline__ void list_scan(const PtKernelArgs& A, const Path& p, bool scan_lane, Hit& h) {
-  const V3& o = p.o; const V3& d = p.d; const float a = p.a;
-  float& closest = h.closest; int& hit = h.hit; uint32_t& lit_from = h.lit_from;
+  const V3 o = p.o; const V3 d = p.d; const float a = p.a;
+  float closest = h.closest; int hit = h.hit; uint32_t lit_from = h.lit_from;
   const uint32_t n_spheres = A.n_spheres;
   uint32_t q_cnt = 0, q0 = 0, q1 = 0, q2 = 0; // candidate queue, newest in the low half of q0
   auto note_candidate = [&](uint32_t idx, float half_b, float c) {
@@ -180,13 +182,68 @@ __device__ __forceinline__ void list_scan(const PtKernelArgs& A, const Path& p, 
       }
     }
   }
+  h.closest = closest; h.hit = hit; h.lit_from = lit_from;
+}
+
+// SMALL LISTS (at most 16 spheres: the reference's own regime, `uniform Sphere[15] u_sphere_list`,
+// static/shader.frag:103).  No LDS copy, no candidate queue: the list is read four spheres at a time
+// with ONE wave-uniform s_load_dwordx16 through the scalar cache (the data reach the VALU as SGPR
+// operands), every group runs the literal cheap half (sphere_test) on all four, and the lanes
+// finish THEIR candidates of the group at once, in lockstep, from the values still in registers
+// (no re-gather, no re-test) — in ascending list order, so the acceptance is the shader's own
+// sequential rule (:159-161): accept iff MIN_T <= v <= closest-so-far, which hands ties to the
+// LATER sphere exactly as the shader's loop does.  A candidate is skipped only when the shader
+// would reject it too (discriminant < 0, or both roots <= 0: see the note at the top).  Padding
+// entries (index >= n) are masked.  Regular rays only; the others take the literal loop.
+template <typename S>
+__device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p, bool scan_lane, Hit& h) {
+  const V3 o = p.o; const V3 d = p.d; const float a = p.a;
+  float closest = h.closest; int hit = h.hit;
+  const uint32_t n_spheres = A.n_spheres;
+  const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
+  const uint32_t a_guard = hit_root_guard(a);
+  const_f4v* c_geom = (const_f4v*)A.geom;
+  auto passes = [](float hb, float cc, float ds) -> bool { return !(ds < 0.0f) && !(cc > 0.0f && hb >= 0.0f); };
+#pragma unroll
+  for (uint32_t g = 0; g < 4u; g++) {
+    const uint32_t base = 4u * g;
+    if (base < n_spheres) { // wave-uniform
+      const f4v e0 = c_geom[base], e1 = c_geom[base + 1u], e2 = c_geom[base + 2u], e3 = c_geom[base + 3u];
+      float hb0, cc0, ds0; sphere_test(o, d, a, e0, hb0, cc0, ds0);
+      float hb1, cc1, ds1; sphere_test(o, d, a, e1, hb1, cc1, ds1);
+      float hb2, cc2, ds2; sphere_test(o, d, a, e2, hb2, cc2, ds2);
+      float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
+      uint32_t mask = 0u;
+      if (scan_lane) {
+        mask = (passes(hb0, cc0, ds0) ? 1u : 0u) | (passes(hb1, cc1, ds1) ? 2u : 0u) |
+               (passes(hb2, cc2, ds2) ? 4u : 0u) | (passes(hb3, cc3, ds3) ? 8u : 0u);
+        const uint32_t left = n_spheres - base; // >= 1, wave-uniform
+        mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
+      }
+      for (;;) {
+        if (pt_ballot(mask != 0u) == 0ull) break;
+        if (mask != 0u) {
+          const uint32_t k = (uint32_t)__builtin_ctz(mask); // ascending list order
+          mask &= mask - 1u;
+          const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
+          const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));
+          const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161
+          if (!(v < PT_MIN_T) && v <= closest) { // :159-161, sequentially: a later sphere at the same root wins
+            closest = v;
+            hit = (int)(base + k);
+          }
+        }
+      }
+    }
+  }
+  h.closest = closest; h.hit = hit;
 }
 
 // PHASE 3: the shader's loop verbatim for whatever the queue / the walk does not cover (rare)
 template <typename S>
 __device__ __forceinline__ void literal_loop(const PtKernelArgs& A, const Path& p, Hit& h) {
-  const V3& o = p.o; const V3& d = p.d; const float a = p.a; const bool alive = p.alive;
-  float& closest = h.closest; int& hit = h.hit; const uint32_t lit_from = h.lit_from;
+  const V3 o = p.o; const V3 d = p.d; const float a = p.a; const bool alive = p.alive;
+  float closest = h.closest; int hit = h.hit; const uint32_t lit_from = h.lit_from;
   const uint32_t n_spheres = A.n_spheres;
   const bool lit = alive && lit_from < n_spheres;
   unsigned long long lit_mask = pt_ballot(lit);
@@ -218,6 +275,7 @@ __device__ __forceinline__ void literal_loop(const PtKernelArgs& A, const Path& 
       }
     }
   }
+  h.closest = closest; h.hit = hit;
 }
 
 } // namespace ptk

@@ -31,11 +31,11 @@ __device__ __forceinline__ PixelDiv pixel_div() {
 // the pixel jitter is divided by the image size (:367-368)
 __device__ __forceinline__ void start_sample(Path& p, const PixelDiv& pd) {
   karg_t& K = *kargs();
-  float& seed = p.seed;
+  float seed = p.seed;  // (local copies, written back at the end: see pt_grid_walk.hpp)
   const float st_s = p.st_s, st_t = p.st_t;
   const bool wh_ok = pd.wh_ok;
   const float y_fw = pd.y_fw, y_fh = pd.y_fh;
-  V3& o = p.o; V3& d = p.d; float& a = p.a; V3& col = p.col; int& depth = p.depth;
+  V3 o, d; float a; V3 col; int depth;
   float r0, r1;
   hash2(seed, r0, r1);
   float jx, jy;
@@ -43,23 +43,45 @@ __device__ __forceinline__ void start_sample(Path& p, const PixelDiv& pd) {
   else { jx = r0 / K.fw; jy = r1 / K.fh; }
   float s = st_s + jx;
   float t = st_t + jy;
-  float ua = hash1(seed); // random_in_unit_circle :123-129, consumed even if lens_radius == 0
-  float sa, ca;
-  sincos2pi(ua, sa, ca);
-  float rr = sqrt_rn(hash1(seed));
-  float rdx = K.lens_radius * (rr * ca);
-  float rdy = K.lens_radius * (rr * sa);
-  V3 off = mk(fma_(K.cam_v[0], rdy, K.cam_u[0] * rdx), fma_(K.cam_v[1], rdy, K.cam_u[1] * rdx),
-              fma_(K.cam_v[2], rdy, K.cam_u[2] * rdx));
   V3 dd = mk(fma_(t, K.vertical[0], fma_(s, K.horizontal[0], K.llc[0])),
              fma_(t, K.vertical[1], fma_(s, K.horizontal[1], K.llc[1])),
              fma_(t, K.vertical[2], fma_(s, K.horizontal[2], K.llc[2])));
   const V3 cam_o = mk(K.origin[0], K.origin[1], K.origin[2]);
-  d = mk((dd.x - cam_o.x) - off.x, (dd.y - cam_o.y) - off.y, (dd.z - cam_o.z) - off.z);
-  o = mk(cam_o.x + off.x, cam_o.y + off.y, cam_o.z + off.z);
+  const V3 tt = mk(dd.x - cam_o.x, dd.y - cam_o.y, dd.z - cam_o.z);
+  // random_in_unit_circle :123-129 draws twice whatever the lens: the seed takes its four steps here,
+  // the draws themselves are made below from a copy, where their values are needed
+  float seed_l = seed;
+  seed = (seed + 0.1f) + 0.1f;
+  seed = (seed + 0.1f) + 0.1f;
+  // LENS OFF (aperture 0: State::default, src/state.rs:102,123).  Then rd = 0 * (...) and the offset
+  // off = u * rd.x + v * rd.y is a vector of zeros of either sign: origin + off is the origin bit for
+  // bit (its components are not -0: host-checked, as is that u and v are finite), and tt - off is tt
+  // unless a component of tt is exactly -0, where the result takes its sign from off — if that
+  // happens anywhere in the wave (it practically never does) the wave runs the full form below.
+  bool lens = K.lens_off == 0u; // wave-uniform
+  if (!lens) {
+    const uint32_t nz = 0x80000000u;
+    lens = pt_ballot(f2u(tt.x) == nz || f2u(tt.y) == nz || f2u(tt.z) == nz) != 0ull;
+  }
+  if (lens) {
+    float ua = hash1(seed_l);
+    float sa, ca;
+    sincos2pi(ua, sa, ca);
+    float rr = sqrt_rn(hash1(seed_l));
+    float rdx = K.lens_radius * (rr * ca);
+    float rdy = K.lens_radius * (rr * sa);
+    V3 off = mk(fma_(K.cam_v[0], rdy, K.cam_u[0] * rdx), fma_(K.cam_v[1], rdy, K.cam_u[1] * rdx),
+                fma_(K.cam_v[2], rdy, K.cam_u[2] * rdx));
+    d = mk(tt.x - off.x, tt.y - off.y, tt.z - off.z);
+    o = mk(cam_o.x + off.x, cam_o.y + off.y, cam_o.z + off.z);
+  } else {
+    d = tt;
+    o = cam_o;
+  }
   a = dot3(d, d);
   col = mk(1.0f, 1.0f, 1.0f);
   depth = 0;
+  p.seed = seed; p.o = o; p.d = d; p.a = a; p.col = col; p.depth = depth;
 }
 
 // ---- refill: lanes without a ray pull work items -------------------------------------------------
@@ -74,11 +96,13 @@ __device__ __forceinline__ void start_sample(Path& p, const PixelDiv& pd) {
 template <bool COUNT>
 __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q, const PixelDiv& pd, Tally<COUNT>& tally) {
   karg_t& K = *kargs();
-  bool& alive = p.alive; bool& exhausted = p.exhausted; bool& new_path = p.new_path;
-  uint32_t& slab_index = p.slab_index; uint32_t& item_tile = p.item_tile; uint32_t& item_segs = p.item_segs;
-  int& sample = p.sample; float& seed = p.seed; float& st_s = p.st_s; float& st_t = p.st_t; V3& sum = p.sum;
-  uint32_t& pool_next = q.pool_next; uint32_t& pool_end = q.pool_end; uint32_t& refill_waited = q.refill_waited;
-  uint32_t& pool_tp0 = q.pool_tp0; uint32_t& pool_split = q.pool_split; uint32_t& pool_tile0 = q.pool_tile0; uint32_t& pool_tile1 = q.pool_tile1;
+  // (local copies, written back at the end: see pt_grid_walk.hpp)
+  bool alive = p.alive, exhausted = p.exhausted, new_path = p.new_path;
+  uint32_t slab_index = p.slab_index, item_tile = p.item_tile, item_segs = p.item_segs;
+  int sample = p.sample; float seed = p.seed, st_s = p.st_s, st_t = p.st_t; V3 sum = p.sum;
+  uint32_t pool_next = q.pool_next, pool_end = q.pool_end, refill_waited = q.refill_waited;
+  uint32_t pool_tp0 = q.pool_tp0, pool_split = q.pool_split, pool_tile0 = q.pool_tile0, pool_tile1 = q.pool_tile1;
+  uint32_t q_round = q.round;
   const bool wh_ok = pd.wh_ok;
   const float y_fw = pd.y_fw, y_fh = pd.y_fh;
   // (`waited` is reset after the loop, not inside it: a loop-carried value that becomes invariant after
@@ -97,11 +121,20 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     dealt = true;
     if (pool_next == pool_end) { // wave-uniform
       unsigned long long base = 0;
-      if (lane_id() == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
-      // wave-uniform, and known to the compiler as such (readfirstlane): the pool bookkeeping derived
-      // from it then lives in SGPRs instead of occupying VGPRs for the kernel's lifetime
-      base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
-             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+      if (K.queue_static != 0u) {
+        // short launches: reservations are dealt round-robin, no atomics (a wave's number is uniform
+        // across its lanes: readfirstlane says so to the compiler)
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) +
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        base = ((unsigned long long)q_round * K.n_waves + wave) * (unsigned long long)A.queue_chunk;
+        q_round++;
+      } else {
+        if (lane_id() == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
+        // wave-uniform, and known to the compiler as such (readfirstlane): the pool bookkeeping derived
+        // from it then lives in SGPRs instead of occupying VGPRs for the kernel's lifetime
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+      }
       if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
         tally.queue_dry();
         if (need) exhausted = true;
@@ -152,15 +185,21 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
         float vx, vy;
         if (wh_ok) { vx = div_core(fx2, K.fw, y_fw) - 1.0f; vy = div_core(fy2, K.fh, y_fh) - 1.0f; }
         else { vx = fx2 / K.fw - 1.0f; vy = fy2 / K.fh - 1.0f; }
-        float u_time = K.time0 + (float)(K.first_pass + pass) * K.time_step;
+        // frames replayed from a hipGraph (pt_render_frames) count on the device: scalar load, constant within a launch
+        const uint32_t frame_k = *(const uint32_t __attribute__((address_space(4)))*)K.frame_ctr;
+        float u_time = K.time0 + (float)(K.first_pass + pass + frame_k) * K.time_step;
         // init_global_seed, static/shader.frag:354-357
         seed = (float)base_hash(f2u(vx), f2u(vy)) * (1.0f / 4294967296.0f) + u_time;
         st_s = (vx + 1.0f) * 0.5f; // :410
         st_t = (vy + 1.0f) * 0.5f;
         slab_index = (pass * K.local_rows + ly) * K.width + px;
         // only the launch's first pass reports its cost (atomicMax per pixel: the tile's
-        // heaviest item): plenty for ordering tiles, and a memory-side atomic moves 64 B
-        item_tile = pass == 0u ? tile : 0xffffffffu;
+        // heaviest item): plenty for ordering tiles, and a memory-side atomic moves 64 B.  Launches of
+        // one short pass (the reference's 1-spp frame) report nothing: there EVERY item would, the 64
+        // lanes of a tile on one address, and — loads, stores and atomics complete in order — the next
+        // material load of each wave would wait for them (measured on the 1280x702 1-spp frame:
+        // 85 % of the wave time in s_waitcnt).
+        item_tile = (pass == 0u && K.cost_feedback != 0u) ? tile : 0xffffffffu;
         item_segs = 0;
         sum = mk(0.f, 0.f, 0.f);
         sample = 0;
@@ -171,6 +210,12 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     }
   }
   refill_waited = (dealt ? 0u : refill_waited) + (put_off ? 1u : 0u);
+  p.alive = alive; p.exhausted = exhausted; p.new_path = new_path;
+  p.slab_index = slab_index; p.item_tile = item_tile; p.item_segs = item_segs;
+  p.sample = sample; p.seed = seed; p.st_s = st_s; p.st_t = st_t; p.sum = sum;
+  q.pool_next = pool_next; q.pool_end = pool_end; q.refill_waited = refill_waited;
+  q.pool_tp0 = pool_tp0; q.pool_split = pool_split; q.pool_tile0 = pool_tile0; q.pool_tile1 = pool_tile1;
+  q.round = q_round;
 }
 
 } // namespace ptk

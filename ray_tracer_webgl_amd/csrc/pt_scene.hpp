@@ -58,6 +58,7 @@ struct Queue {
   uint32_t pool_next = 0, pool_end = 0;  // this wave's reserved queue items
   uint32_t refill_waited = 0;            // steps the waiting lanes have been put off
   uint32_t pool_tp0 = 0, pool_split = 0, pool_tile0 = 0, pool_tile1 = 0;  // the reservation's tile(s)
+  uint32_t round = 0;                    // static dealing (A.queue_static): reservations this wave has taken
 };
 
 // ---- the closest hit of the current segment (hit_world's HitRecord, reduced to what shading needs) --
@@ -84,7 +85,7 @@ struct BvhWalk {  // cursor, queued leaves (8 x 16 bit), queued candidates (8 x 
   uint32_t cur = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_cnt = 0;
   uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q_cnt = 0;
 };
-struct GridWalk {  // boundary-crossing times, linear cell index, steps left per axis (3 x 10 bit, +1),
+struct GridWalk {  // boundary-crossing times, linear cell index, steps left per axis (3 x 10 bit, each + 1),
                    // the cell being tested (first untested entry | entries left << 24), its exit time
   float tmx = 0.f, tmy = 0.f, tmz = 0.f, t_exit = 0.f;
   uint32_t cell = 0, rem = 0, pend = 0;
@@ -105,14 +106,17 @@ struct GridWalk {  // boundary-crossing times, linear cell index, steps left per
 //                1..3  the hierarchy of pt_bvh.hpp: 1 = nodes and slots staged in LDS, 2 = nodes
 //                      in LDS, slots in global memory / L2, 3 = both in global memory;
 //                4..6  the uniform grid of pt_grid.hpp: 4 = cells and entries staged in LDS,
-//                      5 = cells in LDS, entries in global memory / L2, 6 = both global.
+//                      5 = cells in LDS, entries in global memory / L2, 6 = both global;
+//                7     no structure and no LDS copy: a list of at most 16 spheres (the reference's
+//                      u_sphere_list[15], static/shader.frag:103) tested group by group from SGPRs.
 //              List-order reads (tail mode, PHASE 3, shading) go to the global copy.
 template <bool SCAN_LDS_, bool HAVE_LDS_, int WALK_>
 struct Scene {
   static constexpr bool SCAN_LDS = SCAN_LDS_, HAVE_LDS = HAVE_LDS_;
   static constexpr int WALK = WALK_;
   static constexpr bool BVH = WALK >= 1 && WALK <= 3;
-  static constexpr bool GRID = WALK >= 4;
+  static constexpr bool GRID = WALK >= 4 && WALK <= 6;
+  static constexpr bool SMALL = WALK == 7;   // at most 16 spheres, tested straight from SGPRs (pt_list.hpp small_scan)
   static constexpr bool TREE = BVH || GRID;  // a culling structure: hits are (slot, value) pairs
   static constexpr int BVH_MODE = BVH ? WALK : 0;
   static constexpr bool NODES_LDS = WALK == 1 || WALK == 2;

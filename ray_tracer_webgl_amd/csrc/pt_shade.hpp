@@ -18,10 +18,12 @@ namespace ptk {
 // material record are read instead of going through the list index
 template <typename S>
 __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, const Hit& h, const Carry& cw) {
-  bool& alive = p.alive; bool& new_path = p.new_path;
-  const uint32_t slab_index = p.slab_index; const uint32_t item_tile = p.item_tile; uint32_t& item_segs = p.item_segs;
-  int& sample = p.sample; int& depth = p.depth; float& seed = p.seed;
-  V3& o = p.o; V3& d = p.d; float& a = p.a; V3& col = p.col; V3& sum = p.sum;
+  // local copies, written back at the end (see pt_grid_walk.hpp: references would be memory to the
+  // passes that run before inlining)
+  bool alive = p.alive, new_path = p.new_path;
+  const uint32_t slab_index = p.slab_index; const uint32_t item_tile = p.item_tile; uint32_t item_segs = p.item_segs;
+  int sample = p.sample, depth = p.depth; float seed = p.seed;
+  V3 o = p.o, d = p.d; float a = p.a; V3 col = p.col, sum = p.sum;
   const float closest = h.closest; const int hit = h.hit; const uint32_t hit_pos = cw.hit_pos;
   (void)hit_pos;
   item_segs++;
@@ -147,6 +149,9 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       new_path = true;
     }
   }
+  p.alive = alive; p.new_path = new_path; p.item_segs = item_segs;
+  p.sample = sample; p.depth = depth; p.seed = seed;
+  p.o = o; p.d = d; p.a = a; p.col = col; p.sum = sum;
 }
 
 } // namespace ptk

@@ -28,7 +28,12 @@ def gather_rows(local, height, band_rows, rank, world, group=None):
 
     local: torch tensor (local_rows_or_more, width, 4) float32 on the rank's device (cuda for
     nccl, cpu for gloo).  Returns a (height, width, 4) tensor on the same device, identical on
-    every rank."""
+    every rank.
+
+    Stream-ordered and NOT re-entrant: the padded send buffer and the receive buffer are cached per
+    (image, partition, device, process group) and reused by the next call, so a second gather with
+    the same key must not be in flight on another stream or thread while this one runs (bench.py and
+    the tests call it from one thread on the current stream).  The returned tensor is a fresh copy."""
     import torch
     import torch.distributed as dist
 
@@ -38,7 +43,8 @@ def gather_rows(local, height, band_rows, rank, world, group=None):
         return local[:rows_here].clone()
     # buffers and the de-interleave permutation are built once per (image, partition, device):
     # inside a timed frame the gather is one copy, one collective and one index_select
-    key = (int(height), int(width), int(band_rows), int(rank), int(world), str(local.device), local.dtype)
+    key = (int(height), int(width), int(band_rows), int(rank), int(world), str(local.device), local.dtype,
+           id(group) if group is not None else 0)
     ent = _GATHER_CACHE.get(key)
     if ent is None:
         pad_rows = max_local_rows(height, band_rows, world)

@@ -41,7 +41,10 @@ class PathTracer:
 
             self._torch = torch
             stream = torch.cuda.current_stream(self.device)
-            self._check(self.lib.pt_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)))
+            # torch's default stream is the NULL stream, and NULL means "the context's own stream" in this
+            # ABI: name it as hipStreamLegacy (1).  Kernels must run on the stream torch orders its own work
+            # on, or a gather / .cpu() right after render_passes reads the buffer before they have written it.
+            self._check(self.lib.pt_set_stream(self._ctx, C.c_void_p(stream.cuda_stream or abi.PT_STREAM_LEGACY)))
 
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, rc):
@@ -137,6 +140,39 @@ class PathTracer:
 
     def synchronize(self):
         self._check(self.lib.pt_synchronize(self._ctx))
+
+    # -- the reference's frame on device-resident textures ---------------------------------------
+    def clear_textures(self):
+        self._check(self.lib.pt_clear_textures(self._ctx))
+
+    def render_frame(self, even_odd_count):
+        """One animation tick (src/lib.rs:92-102) with the current uniforms: trace one pass, blend
+        with texture[(even_odd_count + 1) % 2], draw to the canvas (and, when averaging, to the
+        other texture).  Asynchronous; nothing crosses PCIe."""
+        self._check(self.lib.pt_render_frame(self._ctx, int(even_odd_count) & 0xFFFFFFFF))
+
+    def render_frames(self, even_odd_count, max_render_count, n_frames):
+        """n ticks at the constant frame interval params.time_step, replayed from one hipGraph with
+        the per-frame state (u_time, render_count, even/odd) counted on the device."""
+        self._check(self.lib.pt_render_frames(self._ctx, int(even_odd_count) & 0xFFFFFFFF, int(max_render_count), int(n_frames)))
+
+    def read_canvas(self):
+        out = np.empty((self.local_rows, self.width, 4), dtype=np.uint8)
+        if out.size:
+            self._check(self.lib.pt_read_canvas(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_texture(self, index):
+        out = np.empty((self.local_rows, self.width, 4), dtype=np.uint8)
+        if out.size:
+            self._check(self.lib.pt_read_texture(self._ctx, int(index), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def write_texture(self, index, rgba8):
+        a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        if a.shape != (self.local_rows, self.width, 4):
+            raise ValueError("texture is %s, this context holds %s" % (a.shape, (self.local_rows, self.width, 4)))
+        self._check(self.lib.pt_write_texture(self._ctx, int(index), a.ctypes.data_as(C.c_void_p)))
 
     # -- read-out -------------------------------------------------------------------------------
     def resolve(self, gamma=True):

@@ -26,13 +26,20 @@ def child():
              ("c4lds", scenes.config4(1024, 1024, 64, 8, 50), 8, abi.PT_GEOM_LDS, 2),
              ("c5grid", scenes.config5(1920, 1080, 64, 4, 50), 4, abi.PT_GEOM_GRID, 3),
              ("default", scenes.default_scene(1280, 702, 25, 8, 16), 16, abi.PT_GEOM_SCALAR, 3),
-             ("default1", scenes.default_scene(1280, 702, 1, 8, 1), 1, abi.PT_GEOM_SCALAR, 5)]
+             ("default1", scenes.default_scene(1280, 702, 1, 8, 1), 1, abi.PT_GEOM_SCALAR, 5),
+             ("c4small", scenes.config4(1024, 1024, 64, 8, 50), 8, abi.PT_GEOM_SMALL, 2),
+             ("defsmall", scenes.default_scene(1280, 702, 25, 8, 16), 16, abi.PT_GEOM_SMALL, 3),
+             ("def1small", scenes.default_scene(1280, 702, 1, 8, 1), 1, abi.PT_GEOM_SMALL, 5)]
     for name, sc, n, path, reps in cases:
         if sel and name not in sel:
             continue
         sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
         pt = PathTracer(sc.params.width, sc.params.height)
-        pt.set_geometry_path(path)
+        try:
+            pt.set_geometry_path(path)
+        except Exception:  # a build that does not know this path
+            pt.close()
+            continue
         pt.set_spheres(sc.spheres)
         pt.set_params(sc.params)
         pt.reserve_passes(n)
@@ -61,6 +68,10 @@ def main():
                 res.setdefault(k, {}).setdefault(lib, []).append((float(ms), int(seg)))
     print("%-10s %s" % ("case", "  ".join("%26s" % os.path.basename(x) for x in libs)) + "   B/A")
     for k, v in res.items():
+        if any(lib not in v for lib in libs):
+            only = [lib for lib in libs if lib in v][0]
+            print("%-10s only in %s: %s" % (k, os.path.basename(only), " ".join("%.3f" % x[0] for x in v[only])))
+            continue
         a = min(x[0] for x in v[libs[0]])
         b = min(x[0] for x in v[libs[1]])
         segs = {x[1] for lib in libs for x in v[lib]}

@@ -1,6 +1,8 @@
 """Dev tool: the bench's config-2 frame as one context vs as two row bands (same process, sequential)."""
 import hashlib, os, sys
 import numpy as np
+import torch
+torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ray_tracer_webgl_amd import abi, dist as ptdist, scenes
 from ray_tracer_webgl_amd.tracer import PathTracer
@@ -34,3 +36,15 @@ for use_torch, reserve in ((False, 64), (True, 64), (True, 128)):
         y = bad[0]
         xs = np.nonzero((out[y].view(np.uint32) != full[y].view(np.uint32)).any(axis=1))[0]
         print("  row", y, "pixels differing", len(xs), xs[:8], out[y, xs[0]], full[y, xs[0]])
+
+# the frame bench.py --gpus 2 --backend gloo --same-device hashed, if it was dumped (PT_BENCH_DUMP)
+dump = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench2_frame.npy")
+if os.path.exists(dump):
+    b = np.load(dump)
+    bad = np.nonzero((b.view(np.uint32) != full.view(np.uint32)).any(axis=(1, 2)))[0]
+    print("bench 2-rank frame:", hashlib.sha256(b.tobytes()).hexdigest(), "rows differing:", len(bad), bad[:24])
+    if len(bad):
+        y = bad[0]
+        xs = np.nonzero((b[y].view(np.uint32) != full[y].view(np.uint32)).any(axis=1))[0]
+        print("  row", y, "pixels differing", len(xs), xs[:8], b[y, xs[0]], full[y, xs[0]])
+        print("  rows mod 8:", np.bincount(bad % 8, minlength=8))
