@@ -86,6 +86,13 @@ enum {
                              0 = lockstep.  Default 12. */
   PT_OPT_REFILL_MIN = 4,  /* lanes of a busy wave that wait for a new work item before the (wave-wide) item
                              decode runs for them.  Scheduling only.  1 = refill at once.  Default 4. */
+  PT_OPT_RUSSIAN_ROULETTE = 5, /* value k > 0: after k bounces a path survives each further bounce with
+                             probability q = min(max(throughput), 1) and carries throughput / q (unbiased:
+                             every pixel's EXPECTATION is the reference's, depth-exhaustion term included).
+                             NOT the reference's estimator sample for sample — static/shader.frag:297-339
+                             never ends a path early — so images of this mode match the oracle only
+                             statistically; it exists for deep-bounce scenes (BASELINE config 4: mean path
+                             length 40 segments).  0 = off (default): bit-exact against the oracle. */
 };
 
 /* ---- background modes ----------------------------------------------------------------------- */

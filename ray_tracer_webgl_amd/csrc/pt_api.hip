@@ -90,6 +90,7 @@ struct pt_ctx {
   size_t wave_log_cap = 0, wave_log_n = 0;
   uint32_t carry_lanes = 12;
   uint32_t refill_min = 4;
+  int rr_min_depth = 0;  // PT_OPT_RUSSIAN_ROULETTE: 0 = off (the reference's estimator, bit-exact against the oracle)
   // work-queue ordering feedback
   uint32_t* d_tile_cost = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -243,6 +244,10 @@ void list_paths(pt_ctx* c) {
   if (c->have_grid && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_GRID;
 }
 
+#define PT_KFN(name) reinterpret_cast<const void*>(name)
+// the Russian-roulette build of a kernel when the option is on
+#define PT_PICK(rr, name) ((rr) ? PT_KFN(name##_rr) : PT_KFN(name))
+
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
   uint32_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -311,7 +316,9 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   for (const void* k : {reinterpret_cast<const void*>(pt_trace_kernel_grid), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells),
                         reinterpret_cast<const void*>(pt_trace_kernel_grid_gmem), reinterpret_cast<const void*>(pt_trace_kernel_bvh_count),
-                        reinterpret_cast<const void*>(pt_trace_kernel_grid_count), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count)})
+                        reinterpret_cast<const void*>(pt_trace_kernel_grid_count), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count),
+                        PT_KFN(pt_trace_kernel_scalar_rr), PT_KFN(pt_trace_kernel_bvh_rr), PT_KFN(pt_trace_kernel_bvh_nodes_rr),
+                        PT_KFN(pt_trace_kernel_grid_rr), PT_KFN(pt_trace_kernel_grid_cells_rr)})
     (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipGetLastError(); // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
   int rc = ensure_buffers(c);
@@ -702,6 +709,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   A.first_pass = p.first_pass;
   A.spp = p.samples_per_pixel;
   A.max_depth = p.max_depth;
+  A.rr_min_depth = c->rr_min_depth;
   A.background_mode = p.background_mode;
   A.width = c->width;
   A.height = c->height;
@@ -748,6 +756,9 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   if (path == PT_GEOM_BVH && !c->have_bvh) path = PT_GEOM_SCALAR;
   if (path == PT_GEOM_SMALL && c->n_spheres > PT_MAX_SPHERES_SMALL) path = PT_GEOM_SCALAR;
   if (path == PT_GEOM_LDS && c->n_spheres > PT_MAX_SPHERES_LDS) path = PT_GEOM_SCALAR;
+  const bool rr = c->rr_min_depth > 0;
+  if (rr && path == PT_GEOM_LDS) path = PT_GEOM_SCALAR;  // the roulette builds exist for the other four ways to read the list
+  if (rr && c->count_work) return fail(c, PT_ERR_INVALID, "PT_OPT_COUNT_WORK and PT_OPT_RUSSIAN_ROULETTE exclude each other");
   c->geom_last = path;
   // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
   // per CU when the staged data takes most of the 160 KiB LDS
@@ -783,13 +794,12 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
       const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
       if (need_all + park1024 <= lds_max) {
         scene = need_all;
-        kfn = c->count_work ? reinterpret_cast<const void*>(pt_trace_kernel_bvh_count)
-                            : reinterpret_cast<const void*>(pt_trace_kernel_bvh);
+        kfn = c->count_work ? PT_KFN(pt_trace_kernel_bvh_count) : PT_PICK(rr, pt_trace_kernel_bvh);
       } else if (need_nodes + park1024 <= lds_max) {
         scene = need_nodes;
-        kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_nodes);
+        kfn = PT_PICK(rr, pt_trace_kernel_bvh_nodes);
       } else {
-        kfn = reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem);
+        kfn = PT_PICK(rr, pt_trace_kernel_bvh_gmem);
       }
     } else {
       const ptgrid::Grid& g = c->grid;
@@ -814,14 +824,12 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
       const size_t need_all = need_cells + (size_t)g.n_entries * 16;
       if (need_all + park1024 <= lds_max) {
         scene = need_all;
-        kfn = c->count_work ? reinterpret_cast<const void*>(pt_trace_kernel_grid_count)
-                            : reinterpret_cast<const void*>(pt_trace_kernel_grid);
+        kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_count) : PT_PICK(rr, pt_trace_kernel_grid);
       } else if (need_cells + park1024 <= lds_max) {
         scene = need_cells;
-        kfn = c->count_work ? reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count)
-                            : reinterpret_cast<const void*>(pt_trace_kernel_grid_cells);
+        kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_cells_count) : PT_PICK(rr, pt_trace_kernel_grid_cells);
       } else {
-        kfn = reinterpret_cast<const void*>(pt_trace_kernel_grid_gmem);
+        kfn = PT_PICK(rr, pt_trace_kernel_grid_gmem);
       }
     }
     A.lds_scene_bytes = (uint32_t)scene;
@@ -857,10 +865,9 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
     const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS && path != PT_GEOM_SMALL;
     lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
-    kfn = path == PT_GEOM_SMALL ? reinterpret_cast<const void*>(pt_trace_kernel_small)
-          : path == PT_GEOM_LDS ? reinterpret_cast<const void*>(pt_trace_kernel)
-                                : (have_lds ? reinterpret_cast<const void*>(pt_trace_kernel_scalar)
-                                            : reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds));
+    kfn = path == PT_GEOM_SMALL ? PT_PICK(rr, pt_trace_kernel_small)
+          : path == PT_GEOM_LDS ? PT_KFN(pt_trace_kernel)
+                                : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar) : PT_PICK(rr, pt_trace_kernel_scalar_nolds));
   }
   uint32_t block = bvh_block ? bvh_block : (lds > 40 * 1024 ? 1024u : 256u);
   A.block_threads = block;
@@ -1287,6 +1294,11 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   if (key == PT_OPT_REFILL_MIN) { // scheduling only, never results
     if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: refill min %d", value);
     c->refill_min = (uint32_t)value;
+    return PT_OK;
+  }
+  if (key == PT_OPT_RUSSIAN_ROULETTE) { // changes sample values (not expectations): off unless asked for
+    if (value < 0 || value > 1000000) return fail(c, PT_ERR_INVALID, "pt_set_option: roulette depth %d", value);
+    c->rr_min_depth = value;
     return PT_OK;
   }
   if (key == PT_OPT_CARRY_LANES) { // 0 = lockstep to the last lane; scheduling only, never results

@@ -82,6 +82,7 @@ struct PtKernelArgs {
   float fw, fh;                    // float(width), float(height)
   PtDiv div_per_tile, div_tiles_x, div_band_rows;  // by 64 * n_passes, tiles_x, band_rows
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
+  int32_t rr_min_depth;            // Russian roulette after this many bounces (0 = never: the reference's estimator)
   uint32_t lens_off;               // 1: lens_radius is 0, u and v are finite, no component of the origin is -0 (pt_refill.hpp start_sample)
   uint32_t queue_static;           // 1: no queue atomics — wave w takes the reservations w, w + n_waves, w + 2 n_waves, ...
                                    // (launches of a few items per lane: every reservation of the shared queue is an atomic

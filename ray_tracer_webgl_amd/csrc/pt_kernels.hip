@@ -48,9 +48,10 @@ using namespace ptd;
 
 // --------------------------------------------------------------------------------------------
 // The path-tracing kernel body: one persistent wave working through (pixel, pass) items.
-// Template parameters: pt_scene.hpp `Scene`; COUNT = the measuring twin (tallies live).
+// Template parameters: pt_scene.hpp `Scene`; COUNT = the measuring twin (tallies live); RR = the
+// opt-in Russian-roulette build (pt_shade.hpp).
 // --------------------------------------------------------------------------------------------
-template <bool SCAN_LDS, bool HAVE_LDS, int WALK = 0, bool COUNT = false>
+template <bool SCAN_LDS, bool HAVE_LDS, int WALK = 0, bool COUNT = false, bool RR = false>
 __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   using namespace ptk;
   using S = Scene<SCAN_LDS, HAVE_LDS, WALK>;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     const bool shade = p.alive && !cw.carried;
     seg_count += (uint32_t)__popcll(pt_ballot(shade));
     tally.timebin(A, shade);
-    if (shade) shade_segment<S>(A, p, h, cw);
+    if (shade) shade_segment<S, RR>(A, p, h, cw);
     tally.phase(6);
   }
 
@@ -184,6 +185,35 @@ extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_
 }
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells_count(const PtKernelArgs A) {
   pt_trace_body<false, false, 5, true>(A);
+}
+
+// Russian-roulette builds (PT_OPT_RUSSIAN_ROULETTE, opt-in; same launch shapes as their namesakes)
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 7, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_rr(const PtKernelArgs A) {
+  pt_trace_body<false, true, 0, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 0, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 1, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_nodes_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 2, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 3, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 4, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_cells_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 5, false, true>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem_rr(const PtKernelArgs A) {
+  pt_trace_body<false, false, 6, false, true>(A);
 }
 
 // --------------------------------------------------------------------------------------------

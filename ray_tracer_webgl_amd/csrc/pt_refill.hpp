@@ -122,19 +122,18 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     if (pool_next == pool_end) { // wave-uniform
       unsigned long long base = 0;
       if (K.queue_static != 0u) {
-        // short launches: reservations are dealt round-robin, no atomics (a wave's number is uniform
-        // across its lanes: readfirstlane says so to the compiler)
-        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) +
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        // short launches: reservations are dealt round-robin, no atomics (a wave's number is the same in
+        // all its lanes)
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         base = ((unsigned long long)q_round * K.n_waves + wave) * (unsigned long long)A.queue_chunk;
         q_round++;
       } else {
         if (lane_id() == 0u) base = atomicAdd(&A.counters[PT_CTR_HEAD], (unsigned long long)A.queue_chunk);
-        // wave-uniform, and known to the compiler as such (readfirstlane): the pool bookkeeping derived
-        // from it then lives in SGPRs instead of occupying VGPRs for the kernel's lifetime
-        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
-               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
       }
+      // wave-uniform, and known to the compiler as such (readfirstlane): the pool bookkeeping derived
+      // from it then lives in SGPRs instead of occupying VGPRs for the kernel's lifetime
+      base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
       if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
         tally.queue_dry();
         if (need) exhausted = true;

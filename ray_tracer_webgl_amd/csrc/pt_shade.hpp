@@ -16,7 +16,9 @@ namespace ptk {
 // shade the lanes whose walk / scan has finished (`p.alive && !carried`): the closest hit is
 // (h.closest, h.hit) — walk kernels: the slot cw.hit_pos, whose copy of the sphere and of its
 // material record are read instead of going through the list index
-template <typename S>
+// RR: the opt-in Russian-roulette build of a kernel (PT_OPT_RUSSIAN_ROULETTE); the kernels without it
+// carry none of its code or registers
+template <typename S, bool RR>
 __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, const Hit& h, const Carry& cw) {
   // local copies, written back at the end (see pt_grid_walk.hpp: references would be memory to the
   // passes that run before inlining)
@@ -134,6 +136,24 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       if (depth >= A.max_depth) { // loop bound :300 exhausted -> return color :338
         sum.x += col.x; sum.y += col.y; sum.z += col.z;
         finished = true;
+      }
+      if constexpr (RR) if (!finished && depth >= A.rr_min_depth) {
+        // RUSSIAN ROULETTE — opt-in (PT_OPT_RUSSIAN_ROULETTE), NOT the reference's estimator sample for
+        // sample: static/shader.frag:297-339 never ends a path early.  After rr_min_depth bounces a path
+        // survives with probability q = min(max(throughput), 1) and, if it does, carries throughput / q:
+        // E[throughput'] = q (throughput / q) = throughput, so every pixel's expectation — including the
+        // `return color` term of depth exhaustion — is the reference's; only the variance and the work
+        // change.  One extra hash1 draw per decision, which moves this stream's later random numbers:
+        // images of this mode are compared with the oracle statistically (tests/test_gpu_roulette.py),
+        // never bit for bit.
+        const float q = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(col.x, col.y), col.z), 1.0f);
+        const float xi = hash1(seed);
+        if (!(xi < q)) { // also ends paths whose throughput is 0 or NaN
+          finished = true;
+        } else {
+          const float inv = 1.0f / q;
+          col.x *= inv; col.y *= inv; col.z *= inv;
+        }
       }
     }
   }

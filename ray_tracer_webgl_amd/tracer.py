@@ -116,6 +116,12 @@ class PathTracer:
         Scheduling only: images do not depend on it."""
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_REFILL_MIN, int(n)))
 
+    def set_russian_roulette(self, min_depth):
+        """Opt-in perf mode (0 = off, the default): after `min_depth` bounces a path survives each further
+        bounce with probability min(max(throughput), 1) and is re-weighted.  Same expectation per pixel
+        as the reference's estimator, different samples: never bit-comparable with the oracle."""
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_RUSSIAN_ROULETTE, int(min_depth)))
+
     def tune(self, n_passes):
         """Settle PT_GEOM_AUTO now (one cold + one untimed launch of n_passes passes per usable
         path); clears the accumulation."""
