@@ -51,10 +51,33 @@ extern "C" {
     pub fn pt_read_accum(ctx: *mut PtCtx, dst: *mut f32, bytes: usize) -> c_int;
     pub fn pt_load_accum(ctx: *mut PtCtx, src: *const f32, bytes: usize) -> c_int;
     pub fn pt_set_stream(ctx: *mut PtCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn pt_set_option(ctx: *mut PtCtx, key: c_int, value: c_int) -> c_int;
+    pub fn pt_tune(ctx: *mut PtCtx, n_passes: u32) -> c_int;
+    // the reference's frame on device-resident textures: webgl::render, src/webgl.rs:180-205
+    pub fn pt_clear_textures(ctx: *mut PtCtx) -> c_int;
+    pub fn pt_render_frame(ctx: *mut PtCtx, even_odd_count: u32) -> c_int;
+    pub fn pt_render_frames(ctx: *mut PtCtx, even_odd_count: u32, max_render_count: u32, n_frames: u32) -> c_int;
+    pub fn pt_read_canvas(ctx: *mut PtCtx, rgba_out: *mut u8) -> c_int;
+    pub fn pt_read_texture(ctx: *mut PtCtx, index: c_int, rgba_out: *mut u8) -> c_int;
+    pub fn pt_write_texture(ctx: *mut PtCtx, index: c_int, rgba_in: *const u8) -> c_int;
     pub fn pt_last_error(ctx: *mut PtCtx) -> *const c_char;
     pub fn pt_abi_version() -> c_int;
     pub fn pt_device_count() -> c_int;
 }
+
+pub const PT_OPT_GEOMETRY_PATH: c_int = 1;      // PT_GEOM_AUTO 0 / LDS 1 / SCALAR 2 / BVH 3 / GRID 4 / SMALL 5
+pub const PT_OPT_RUSSIAN_ROULETTE: c_int = 5;   // opt-in, 0 = off: the reference's estimator has none (shader.frag:297-339)
+
+// The rAF closure of src/lib.rs:65-104 with webgl::render replaced (one tick):
+//     state::update_render_globals(&mut state);
+//     let p = PtParams::from_state(&state, now);            // uniforms.run_setters(now)
+//     pt_set_params(ctx, &p);
+//     pt_render_frame(ctx, state.even_odd_count);           // webgl::render: trace + blend into the ping-pong textures
+//     if should_save { pt_read_canvas(ctx, pixels.as_mut_ptr()); }
+// A run of ticks with nothing else happening (no input) is one call:
+//     p.time_step = frame_interval_ms; pt_set_params(ctx, &p);
+//     pt_render_frames(ctx, state.even_odd_count, state.max_render_count, n);   // one hipGraph replayed n times
+//     for _ in 1..n { state::update_render_globals(&mut state); }
 
 // State -> uniforms: what Uniforms::run_setters uploads (src/webgl.rs:279-593)
 impl PtParams {

@@ -206,7 +206,8 @@ def test_rust_binding_lists_the_render_abi():
     for name in ["pt_create", "pt_destroy", "pt_resize", "pt_set_spheres", "pt_set_params", "pt_render",
                  "pt_render_passes", "pt_reserve_passes", "pt_reset_accum", "pt_synchronize", "pt_resolve",
                  "pt_resolve_rgba8", "pt_blend_rgba8", "pt_accum_ptr", "pt_bind_accum", "pt_read_accum", "pt_load_accum",
-                 "pt_set_stream",
+                 "pt_set_stream", "pt_set_option", "pt_tune", "pt_clear_textures", "pt_render_frame", "pt_render_frames",
+                 "pt_read_canvas", "pt_read_texture", "pt_write_texture",
                  "pt_last_error", "pt_abi_version", "pt_device_count"]:
         r = re.search(r"pub fn %s\(([^)]*)\)" % name, text)
         h = re.search(r"\b%s\s*\(([^)]*)\)" % name, header)
