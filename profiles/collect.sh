@@ -7,10 +7,12 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-work-count"   # keeps the list-walk leg: the scalar list kernel is in the same trace
+BENCH="python3 bench.py --no-cpu-baseline --no-work-count"   # the default workload (config 2, 16 steps = 1024 spp); keeps the list-walk leg: the scalar list kernel is in the same trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
 # the other BASELINE configs (one launch each after pt_tune): kernel trace only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_configs -- python3 tools/config_sweep.py config3 config4 config5 default > $OUT/kt_configs.log 2>&1
+# the reference's own operating point: the animation loop replayed from a hipGraph (bench.py --config default)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_frames -- python3 bench.py --config default --frames 200 > $OUT/kt_frames.log 2>&1
 i=0
 for grp in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \

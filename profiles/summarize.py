@@ -21,6 +21,18 @@ for f in glob.glob(os.path.join(d, "kt", "**", "*_kernel_stats.csv"), recursive=
                 float(row["MaxNs"]) / 1e6, row["Percentage"]))
             out.setdefault("kernel_stats", {})[row["Name"]] = {
                 "calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6}
+# the timed launches in the kernel trace of the bench command: per trace kernel, the dispatches within 15 % of
+# its longest (the autotune / first-frame legs launch the same kernels on fewer passes)
+for f in glob.glob(os.path.join(d, "kt", "**", "*_kernel_trace.csv"), recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("pt_trace")]
+    by = defaultdict(list)
+    for r in rows:
+        by[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    print("== full-size dispatches per trace kernel (%s)" % os.path.relpath(f, d))
+    for k, v in sorted(by.items()):
+        full = [x for x in v if x >= 0.85 * max(v)]
+        print("  %-32s %d of %d dispatches full-size: avg %.3f ms  min %.3f  max %.3f" % (k, len(full), len(v), sum(full) / len(full), min(full), max(full)))
+        out.setdefault("kernel_full", {})[k] = {"calls": len(full), "avg_ms": sum(full) / len(full)}
 # the other configs: every trace-kernel dispatch in order (pt_tune's trials of each usable path, then
 # the measured launch = the last dispatch before the next config's first)
 for f in glob.glob(os.path.join(d, "kt_configs", "**", "*_kernel_trace.csv"), recursive=True):
@@ -37,10 +49,20 @@ for f in glob.glob(os.path.join(d, "kt_configs.log")):
     for line in open(f):
         if line.startswith(("config", "default")):
             print("  " + line.rstrip())
+# PMC passes: per kernel, only the FULL-SIZE dispatches count (bench.py's autotune and first-frame legs
+# launch the same kernels on 8 passes; the timed launches are the long ones): a dispatch is kept when its
+# duration is within 15 % of that kernel's longest in the same pass
 ctr = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(d, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        ctr[row["Kernel_Name"]][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+    rows = [r for r in csv.DictReader(open(f))]
+    longest = defaultdict(float)
+    for row in rows:
+        dur = float(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        longest[row["Kernel_Name"]] = max(longest[row["Kernel_Name"]], dur)
+    for row in rows:
+        dur = float(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        if dur >= 0.85 * longest[row["Kernel_Name"]]:
+            ctr[row["Kernel_Name"]][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 main_kernel = None
 if ctr:
     cands = [k for k in ctr if k.startswith("pt_trace")]
@@ -96,7 +118,7 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
             if k in pm:
                 rec[k.lower()] = pm[k]
     # the same kernel's average duration in the kernel-trace pass of the same command
-    ks = out.get("kernel_stats", {}).get(out.get("pmc_kernel"))
+    ks = out.get("kernel_full", {}).get(out.get("pmc_kernel")) or out.get("kernel_stats", {}).get(out.get("pmc_kernel"))
     if ks:
         rec["kernel_ms"] = ks["avg_ms"]
     json.dump(rec, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
