@@ -137,6 +137,23 @@ def spawn_selftest(mode):
     return 0
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner to STDOUT when its first communicator comes up; rank 0's stdout must
+    carry the JSON line and nothing else.  Sends file descriptor 1 to stderr for the duration."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def frame_digest(full):
     """SHA-256 of the (height, width, 4) fp32 radiance frame, as tests/golden/make_full_digests.py
     computes it."""
@@ -229,11 +246,17 @@ def main():
 
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-        ranks_seen = dist.get_world_size()
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            ranks_seen = dist.get_world_size()
+            # bring the communicator up here (RCCL initialises lazily, and talks while it does)
+            t_up = torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t_up)
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
 
     pps_frame = max(1, args.passes_per_step)  # passes per step of the single-GPU workload
     weak = args.scaling == "weak" and world > 1

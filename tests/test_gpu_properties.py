@@ -181,7 +181,9 @@ def _bench(*extra, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_stdout_lines"] = len([ln for ln in r.stdout.splitlines() if ln.strip()])
+    return d
 
 
 def test_bench_two_ranks_on_one_device():
@@ -203,6 +205,16 @@ def test_bench_two_ranks_on_one_device():
     assert ws and ws["scaling"] == "weak" and ws["spp"] == 2 * 1024 and ws["sec"] > 0
     assert abs(d["sec_to_converged_frame"] - d["ms_per_step"] * 16 / 1e3) < 1e-3
     assert d["value"] > 0 and d["segments"] > 0 and d["first_frame_ms"] > 0
+
+
+def test_bench_rccl_path_with_one_rank():
+    """--force-dist: the RCCL code path (init with device_id, all_gather_into_tensor on device buffers,
+    all_reduce of the timings) as far as one GPU allows.  Rank 0's stdout must carry the JSON line and
+    NOTHING else — RCCL prints a version banner to stdout when its communicator comes up — and the frame
+    that went through the collective must hash to the committed digest."""
+    d = _bench("--force-dist", "--no-cpu-baseline", "--no-list-walk", "--no-work-count", "--no-first-frame", "--warmup", "4")
+    assert d["_stdout_lines"] == 1
+    assert d["ranks"] == 1 and d["gather_matches_single_gpu"] is True and d["scaling"] == "strong"
 
 
 def test_bench_weak_scaling_and_small_frames():
