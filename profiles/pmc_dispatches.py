@@ -14,6 +14,7 @@ derived figures DESIGN.md quotes:
     valu_issue_frac  = 2 / cyc_per_valu                          (a wave64 VALU op holds a SIMD 2 cycles)
     lane_util        = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
     cu_coverage      = SQ_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4)    (SQ_BUSY_CYCLES sums the 32 SEs' SQs; 4 per XCD)
+    wave_residency   = 4 * SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8 * SQ_WAVES)   (share of the launch a wave is alive; quad-cycles)
     wait_frac        = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
     salu_per_valu, branch_per_valu, lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
@@ -69,6 +70,8 @@ for k in sorted(table):
             der.append("cyc_per_valu %.3f  valu_issue_frac %.3f" % (cpv, 2.0 / cpv))
         if c.get("SQ_BUSY_CYCLES"):
             der.append("cu_coverage %.3f" % (c["SQ_BUSY_CYCLES"] / (g * 4.0)))
+        if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAVES"):  # SQ_WAVE_CYCLES counts quad-cycles
+            der.append("wave_residency %.3f" % (4.0 * c["SQ_WAVE_CYCLES"] / ((g / 8.0) * c["SQ_WAVES"])))
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
         der.append("lane_util %.3f" % (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])))
     if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES"):
