@@ -1062,3 +1062,27 @@ def test_plain_c_example_matches_python_path(tmp_path):
     t, _ = render_scene(sc)
     assert np.array_equal(t.resolve_rgba8(True)[..., :3], img)
     t.close()
+
+
+def test_plain_c_animation_matches_the_python_frame_loop(tmp_path):
+    """examples/animate.c: the reference's animation loop from plain C — n ticks as ONE pt_render_frames
+    call (one hipGraph replayed n times, per-frame state on the device).  Its canvas must be the canvas of
+    app.FrameLoop driven tick by tick with host-made uniforms."""
+    import subprocess
+
+    from ray_tracer_webgl_amd.app import FrameLoop
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples"), "animate"])
+    out = str(tmp_path / "a.ppm")
+    w, h, n = 128, 72, 12
+    subprocess.check_call([os.path.join(root, "examples", "animate"), out, str(w), str(h), str(n)])
+    data = open(out, "rb").read()
+    header, pix = data.split(b"255\n", 1)
+    img = np.frombuffer(pix, dtype=np.uint8).reshape(h, w, 3)[::-1]
+    loop = FrameLoop(w, h, mode="reference")
+    loop.state.set_flags(is_paused=False)
+    for k in range(n):
+        assert loop.frame(3000.0 + 16.5 * k) is True
+    assert np.array_equal(loop.canvas[..., :3], img)
+    loop.close()
