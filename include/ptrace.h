@@ -71,7 +71,7 @@ enum {
   PT_GEOM_BVH = 3,
   PT_GEOM_GRID = 4,
   PT_GEOM_SMALL = 5, /* lists of at most 16 spheres (the reference's `uniform Sphere[15] u_sphere_list`,
-                        static/shader.frag:103): no LDS copy, no candidate queue — four spheres per
+                        static/shader.frag:103): no LDS traffic in the scan, no candidate queue — four spheres per
                         s_load_dwordx16 reach the VALU as SGPR operands, candidates are finished group by
                         group in list order with the shader's own sequential acceptance.  A longer list
                         falls back to SCALAR.  PT_GEOM_AUTO tries it first on such scenes. */

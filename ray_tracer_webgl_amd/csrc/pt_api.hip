@@ -683,9 +683,9 @@ struct Launch {
   int trial = -1;  // k when this launch is the autotune measurement of trial_paths[k]
 };
 
-static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L) {
+// the shader's uniforms (static/shader.frag:79-99) + this launch's share of the image, as the kernels read them
+static int fill_uniforms(pt_ctx* c, uint32_t n_passes, PtKernelArgs& A) {
   const PtParams& p = c->params;
-  PtKernelArgs& A = L->A;
   memset(&A, 0, sizeof A);
   for (int k = 0; k < 3; k++) {
     A.origin[k] = p.camera_origin[k];
@@ -697,6 +697,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   }
   A.lens_radius = p.lens_radius;
   {
+    // lens arithmetic may be skipped (pt_refill.hpp) when it provably adds +0 everywhere
     bool off = p.lens_radius == 0.0f;
     for (int k = 0; k < 3; k++) {
       off = off && std::isfinite(p.u[k]) && std::isfinite(p.v[k]);
@@ -737,10 +738,27 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   A.counters = c->d_counters;
   A.tile_order = c->d_tile_order;
   A.tile_cost = c->d_tile_cost;
+  A.coop_max_live = 16;
+  A.carry_lanes = c->carry_lanes;
+  A.refill_min = c->refill_min;
+  A.long_item_segments = 6u * (uint32_t)p.samples_per_pixel;
+#ifdef PT_DEV_KNOBS // A/B builds only (tools/sweep_knobs.py); the product reads no environment
+  if (const char* e = getenv("PT_LONG_ITEM")) A.long_item_segments = (uint32_t)atoi(e);
+  if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
+#endif
+  // cost feedback for the next launch's tile order: one atomicMax per item of pass 0.  A launch of one
+  // SHORT pass (the reference's 1-spp frame) would report from every item — the 64 lanes of a tile on
+  // one address — and stall its waves on the atomics (vmcnt completes in order): none there.
+  A.cost_feedback = (n_passes >= 2u || p.samples_per_pixel >= 8) ? 1u : 0u;
+  A.frame_ctr = c->d_frame_ctr + 1;  // the cell that stays 0 (pt_render_frames points at [0])
+  return PT_OK;
+}
 
-  // which way PHASE 1 looks at the sphere list (bit-identical results whichever way)
+// which way PHASE 1 looks at the sphere list (bit-identical results whichever way): the forced path,
+// or PT_GEOM_AUTO's tuned one / the trial this launch is (`*trial` = k when it measures trial_paths[k])
+static int choose_path(pt_ctx* c, bool allow_trials, int* trial) {
   int path = c->geom_policy;
-  int trial = -1; // k when this launch is the autotune measurement of trial_paths[k]
+  *trial = -1;
   if (path == PT_GEOM_AUTO && !allow_trials) {
     try_finish_tuning(c);
     path = c->geom_tuned ? c->geom_tuned : c->trial_paths[0];
@@ -748,7 +766,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     try_finish_tuning(c);
     if (c->geom_tuned) path = c->geom_tuned;
     else if (c->trial_state == 0) { path = c->trial_paths[0]; c->trial_state = 1; } // cold launch: not measured
-    else if (c->trial_state <= c->n_trials) { trial = c->trial_state - 1; path = c->trial_paths[trial]; }
+    else if (c->trial_state <= c->n_trials) { *trial = c->trial_state - 1; path = c->trial_paths[*trial]; }
     else path = c->trial_paths[0]; // trials still in flight
   }
   // a forced path the scene cannot use falls back to the nearest one it can
@@ -756,124 +774,145 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   if (path == PT_GEOM_BVH && !c->have_bvh) path = PT_GEOM_SCALAR;
   if (path == PT_GEOM_SMALL && c->n_spheres > PT_MAX_SPHERES_SMALL) path = PT_GEOM_SCALAR;
   if (path == PT_GEOM_LDS && c->n_spheres > PT_MAX_SPHERES_LDS) path = PT_GEOM_SCALAR;
+  if (c->rr_min_depth > 0 && path == PT_GEOM_LDS) path = PT_GEOM_SCALAR;  // the roulette builds exist for the other four ways to read the list
+  return path;
+}
+
+// hierarchy walk: the tree's arrays and constants; which build of the kernel (everything / the nodes
+// / nothing staged in the LDS); returns the staged bytes
+static size_t bind_hierarchy(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& A, const void** kfn) {
+  A.bvh_nodes = c->d_bvh_nodes;
+  A.bvh_nodes32 = c->d_bvh_nodes32;
+  A.bvh_slots = c->d_bvh_slots;
+  A.bvh_slot_index = c->d_bvh_index;
+  A.slot_mat = c->d_bvh_mat;
+  A.n_nodes = c->bvh_n_nodes;
+  A.n_tree_slots = c->bvh_n_tree_slots;
+  A.n_slots = c->bvh_n_slots;
+  A.n_outliers = c->bvh_n_outliers;
+  for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
+  A.bvh_s0 = c->bvh_s0;
+  A.bvh_kinv = c->bvh_kinv;
+  const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
+  const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
+  if (need_all <= lds_room) {
+    *kfn = c->count_work ? PT_KFN(pt_trace_kernel_bvh_count) : PT_PICK(rr, pt_trace_kernel_bvh);
+    return need_all;
+  }
+  if (need_nodes <= lds_room) {
+    *kfn = PT_PICK(rr, pt_trace_kernel_bvh_nodes);
+    return need_nodes;
+  }
+  *kfn = PT_PICK(rr, pt_trace_kernel_bvh_gmem);
+  return 0;
+}
+
+// grid walk: likewise (cells + entries / the cell records / nothing staged)
+static size_t bind_grid(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& A, const void** kfn) {
+  const ptgrid::Grid& g = c->grid;
+  A.bvh_slots = c->d_grid_entries;
+  A.bvh_slot_index = c->d_grid_index;
+  A.slot_mat = c->d_grid_mat;
+  A.grid_cells = c->d_grid_cells;
+  A.n_cells = g.n[0] * g.n[1] * g.n[2];
+  A.n_tree_slots = g.n_cell_entries;
+  A.n_slots = g.n_entries;
+  A.n_outliers = g.n_always;
+  for (int k = 0; k < 3; k++) {
+    A.bvh_c0[k] = g.c0[k];
+    A.grid_n[k] = g.n[k];
+    A.grid_lo[k] = g.lo[k]; A.grid_hi[k] = g.hi[k];
+    A.grid_h[k] = g.h[k]; A.grid_inv_h[k] = g.inv_h[k];
+    A.grid_lo_n[k] = g.lo_n[k]; A.grid_hi_n[k] = g.hi_n[k];
+  }
+  A.bvh_s0 = g.s0;
+  A.grid_r2_near = g.r2_near;
+  const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
+  const size_t need_all = need_cells + (size_t)g.n_entries * 16;
+  if (need_all <= lds_room) {
+    *kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_count) : PT_PICK(rr, pt_trace_kernel_grid);
+    return need_all;
+  }
+  if (need_cells <= lds_room) {
+    *kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_cells_count) : PT_PICK(rr, pt_trace_kernel_grid_cells);
+    return need_cells;
+  }
+  *kfn = PT_PICK(rr, pt_trace_kernel_grid_gmem);
+  return 0;
+}
+
+// walk kernels: whichever of 256 / 512 / 1024 threads puts the most waves on a CU (the staged scene is
+// paid once per workgroup, the parked path state and the VGPRs per wave)
+static uint32_t walk_block_threads(const void* kfn, size_t scene, size_t lds_max) {
+  uint32_t block = 0;
+  int best_waves = -1;
+  for (uint32_t b = 256; b <= 1024; b *= 2) {
+    const size_t l = scene + (size_t)PT_PARK_STRIDE * 4 * b;
+    if (l > lds_max) continue;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) {
+      (void)hipGetLastError(); // a size this kernel cannot run at: not an error of this call
+      continue;
+    }
+    const int waves = n * (int)(b / 64);
+    if (waves > best_waves) { best_waves = waves; block = b; }
+  }
+#ifdef PT_DEV_KNOBS
+  if (const char* e = getenv("PT_BVH_BLOCK")) {
+    uint32_t b = (uint32_t)atoi(e);
+    if (b >= 64u && b <= 1024u && b % 64u == 0u) block = b;
+  }
+#endif
+  return block ? block : 1024u;
+}
+
+static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L) {
+  PtKernelArgs& A = L->A;
+  {
+    int rc = fill_uniforms(c, n_passes, A);
+    if (rc != PT_OK) return rc;
+  }
+  const unsigned long long items = A.n_items;
+  int trial = -1;
+  const int path = choose_path(c, allow_trials, &trial);
   const bool rr = c->rr_min_depth > 0;
-  if (rr && path == PT_GEOM_LDS) path = PT_GEOM_SCALAR;  // the roulette builds exist for the other four ways to read the list
   if (rr && c->count_work) return fail(c, PT_ERR_INVALID, "PT_OPT_COUNT_WORK and PT_OPT_RUSSIAN_ROULETTE exclude each other");
   c->geom_last = path;
-  // launch geometry: 256-thread workgroups while several fit per CU; one 1024-thread workgroup
-  // per CU when the staged data takes most of the 160 KiB LDS
+
+  // the kernel, its workgroup size and its dynamic LDS (staged scene + the parked path state of every
+  // lane of a walk kernel's workgroup)
   size_t lds = 0;
   const void* kfn = nullptr;
-  uint32_t bvh_block = 0;
-  A.coop_max_live = 16;
-  A.carry_lanes = c->carry_lanes;
-  A.refill_min = c->refill_min;
-  A.long_item_segments = 6u * (uint32_t)p.samples_per_pixel;
-#ifdef PT_DEV_KNOBS
-  if (const char* e = getenv("PT_LONG_ITEM")) A.long_item_segments = (uint32_t)atoi(e);
-#endif
+  uint32_t block = 256;
   if (path == PT_GEOM_BVH || path == PT_GEOM_GRID) {
     const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
-    const size_t park1024 = (size_t)PT_PARK_STRIDE * 4 * 1024;
-    size_t scene = 0;
-    if (path == PT_GEOM_BVH) {
-      A.bvh_nodes = c->d_bvh_nodes;
-      A.bvh_nodes32 = c->d_bvh_nodes32;
-      A.bvh_slots = c->d_bvh_slots;
-      A.bvh_slot_index = c->d_bvh_index;
-      A.slot_mat = c->d_bvh_mat;
-      A.n_nodes = c->bvh_n_nodes;
-      A.n_tree_slots = c->bvh_n_tree_slots;
-      A.n_slots = c->bvh_n_slots;
-      A.n_outliers = c->bvh_n_outliers;
-      for (int k = 0; k < 3; k++) A.bvh_c0[k] = c->bvh_c0[k];
-      A.bvh_s0 = c->bvh_s0;
-      A.bvh_kinv = c->bvh_kinv;
-      // dynamic LDS = staged scene + the parked path state of every lane of the workgroup
-      const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
-      const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
-      if (need_all + park1024 <= lds_max) {
-        scene = need_all;
-        kfn = c->count_work ? PT_KFN(pt_trace_kernel_bvh_count) : PT_PICK(rr, pt_trace_kernel_bvh);
-      } else if (need_nodes + park1024 <= lds_max) {
-        scene = need_nodes;
-        kfn = PT_PICK(rr, pt_trace_kernel_bvh_nodes);
-      } else {
-        kfn = PT_PICK(rr, pt_trace_kernel_bvh_gmem);
-      }
-    } else {
-      const ptgrid::Grid& g = c->grid;
-      A.bvh_slots = c->d_grid_entries;
-      A.bvh_slot_index = c->d_grid_index;
-      A.slot_mat = c->d_grid_mat;
-      A.grid_cells = c->d_grid_cells;
-      A.n_cells = g.n[0] * g.n[1] * g.n[2];
-      A.n_tree_slots = g.n_cell_entries;
-      A.n_slots = g.n_entries;
-      A.n_outliers = g.n_always;
-      for (int k = 0; k < 3; k++) {
-        A.bvh_c0[k] = g.c0[k];
-        A.grid_n[k] = g.n[k];
-        A.grid_lo[k] = g.lo[k]; A.grid_hi[k] = g.hi[k];
-        A.grid_h[k] = g.h[k]; A.grid_inv_h[k] = g.inv_h[k];
-      }
-      A.bvh_s0 = g.s0;
-      A.grid_r2_near = g.r2_near;
-      for (int k = 0; k < 3; k++) { A.grid_lo_n[k] = g.lo_n[k]; A.grid_hi_n[k] = g.hi_n[k]; }
-      const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
-      const size_t need_all = need_cells + (size_t)g.n_entries * 16;
-      if (need_all + park1024 <= lds_max) {
-        scene = need_all;
-        kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_count) : PT_PICK(rr, pt_trace_kernel_grid);
-      } else if (need_cells + park1024 <= lds_max) {
-        scene = need_cells;
-        kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_cells_count) : PT_PICK(rr, pt_trace_kernel_grid_cells);
-      } else {
-        kfn = PT_PICK(rr, pt_trace_kernel_grid_gmem);
-      }
-    }
+    const size_t lds_room = lds_max - (size_t)PT_PARK_STRIDE * 4 * 1024;  // beside a 1024-thread workgroup's parking
+    const size_t scene = path == PT_GEOM_BVH ? bind_hierarchy(c, rr, lds_room, A, &kfn) : bind_grid(c, rr, lds_room, A, &kfn);
     A.lds_scene_bytes = (uint32_t)scene;
     // tail mode costs ~n/64 rounds per live ray, the walk a roughly constant ~1500 issue slots
     // per wave: the turn-around only pays for the last few rays of a wave
-    uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
-    uint32_t lim = 1500u / per_ray;
+    const uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
+    const uint32_t lim = 1500u / per_ray;
     A.coop_max_live = lim > 16u ? 16u : lim;
-    // workgroup size: whichever of 256 / 512 / 1024 threads puts the most waves on a CU (the
-    // staged scene is paid once per workgroup, the parked state and the VGPRs per wave)
-    int best_waves = -1;
-    for (uint32_t b = 256; b <= 1024; b *= 2) {
-      const size_t l = scene + (size_t)PT_PARK_STRIDE * 4 * b;
-      if (l > lds_max) continue;
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) {
-        (void)hipGetLastError(); // a size this kernel cannot run at: not an error of this call
-        continue;
-      }
-      const int waves = n * (int)(b / 64);
-      if (waves > best_waves) { best_waves = waves; bvh_block = b; }
-    }
-#ifdef PT_DEV_KNOBS // A/B builds only (tools/ab_*.sh); the product reads no environment
-    if (const char* e = getenv("PT_BVH_BLOCK")) {
-      uint32_t b = (uint32_t)atoi(e);
-      if (b >= 64u && b <= 1024u && b % 64u == 0u) bvh_block = b;
-    }
-    if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
-#endif
-    if (!bvh_block) bvh_block = 1024u;
-    lds = scene + (size_t)PT_PARK_STRIDE * 4 * bvh_block;
+    block = walk_block_threads(kfn, scene, lds_max);
+    lds = scene + (size_t)PT_PARK_STRIDE * 4 * block;
   } else {
-    // the LDS copy exists whenever the list fits; the scalar walk only changes how the SCAN reads
-    const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS && path != PT_GEOM_SMALL;
+    // the LDS copy exists whenever the list fits; the scalar and small-list walks only change how the
+    // SCAN reads (their per-lane gathers — shading, tail mode — still come from the copy)
+    const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
     lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
     kfn = path == PT_GEOM_SMALL ? PT_PICK(rr, pt_trace_kernel_small)
           : path == PT_GEOM_LDS ? PT_KFN(pt_trace_kernel)
                                 : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar) : PT_PICK(rr, pt_trace_kernel_scalar_nolds));
+    // 256-thread workgroups while several fit per CU; one 1024-thread workgroup per CU when the list
+    // takes most of the 160 KiB LDS
+    block = lds > 40 * 1024 ? 1024u : 256u;
   }
-  uint32_t block = bvh_block ? bvh_block : (lds > 40 * 1024 ? 1024u : 256u);
   A.block_threads = block;
   int per_cu = 0;
   PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
+
   // Items a wave reserves per queue atomic.  Items are numbered tile-major, so a reservation is
   // also a run of neighbouring pixels: big reservations keep a wave's lanes on one tile (more
   // coherent walks, fewer atomics), small ones deal the tail of a short launch finely.
@@ -881,7 +920,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   // lane) 153.6 / 149.9 / 148.0 / 147.3 ms with 64 / 128 / 256 / 512 items; one rank's band of eight
   // (28 items per lane) 24.0 / 22.0 / 21.1 / 21.0 / 21.1 / 21.5 / 22.9 ms with 16 ... 1024.
   {
-    unsigned long long lanes = (unsigned long long)c->num_cus * (unsigned)per_cu * block;
+    const unsigned long long lanes = (unsigned long long)c->num_cus * (unsigned)per_cu * block;
     A.queue_chunk = items >= 192ull * lanes ? 512u : (items >= 64ull * lanes ? 128u : (items >= 16ull * lanes ? 64u : 32u));
 #ifdef PT_DEV_KNOBS
     if (const char* e = getenv("PT_QUEUE_CHUNK")) {
@@ -890,8 +929,8 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     }
 #endif
   }
-  unsigned long long want = (items + block - 1) / block;
-  unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
+  const unsigned long long want = (items + block - 1) / block;
+  const unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
   if (grid < 1) grid = 1;
   // Launches of a few items per lane (the reference's 1-spp frame: two) cannot afford the shared
@@ -903,11 +942,6 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   A.queue_static = items < 8ull * (unsigned long long)A.n_waves * 64ull ? 1u : 0u;
   if (A.queue_static) A.queue_chunk = 64u;
 
-  // cost feedback for the next launch's tile order: one atomicMax per item of pass 0.  A launch of one
-  // SHORT pass (the reference's 1-spp frame) would report from every item — the 64 lanes of a tile on
-  // one address — and stall its waves on the atomics (vmcnt completes in order): none there.
-  A.cost_feedback = (n_passes >= 2u || p.samples_per_pixel >= 8) ? 1u : 0u;
-  A.frame_ctr = c->d_frame_ctr + 1;  // the cell that stays 0 (pt_render_frames points at [0])
   L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;
   return PT_OK;
 }

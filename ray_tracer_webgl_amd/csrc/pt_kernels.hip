@@ -141,10 +141,10 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(
   pt_trace_body<false, false>(A);
 }
 
-// lists of at most 16 spheres (PT_GEOM_SMALL: the reference's own scene size): no LDS, no candidate
+// lists of at most 16 spheres (PT_GEOM_SMALL: the reference's own scene size): no LDS in the scan, no candidate
 // queue, the list reaches the VALU group by group from SGPRs
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small(const PtKernelArgs A) {
-  pt_trace_body<false, false, 7>(A);
+  pt_trace_body<false, true, 7>(A);
 }
 
 // The walk kernels are latency-bound, not issue-bound: for scenes small enough that LDS
@@ -189,7 +189,7 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells_co
 
 // Russian-roulette builds (PT_OPT_RUSSIAN_ROULETTE, opt-in; same launch shapes as their namesakes)
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 7, false, true>(A);
+  pt_trace_body<false, true, 7, false, true>(A);
 }
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 0, false, true>(A);

@@ -186,7 +186,7 @@ __device__ __forceinline__ void list_scan(const PtKernelArgs& A, const Path& p, 
 }
 
 // SMALL LISTS (at most 16 spheres: the reference's own regime, `uniform Sphere[15] u_sphere_list`,
-// static/shader.frag:103).  No LDS copy, no candidate queue: the list is read four spheres at a time
+// static/shader.frag:103).  No LDS traffic in the scan, no candidate queue: the list is read four spheres at a time
 // with ONE wave-uniform s_load_dwordx16 through the scalar cache (the data reach the VALU as SGPR
 // operands), every group runs the literal cheap half (sphere_test) on all four, and the lanes
 // finish THEIR candidates of the group at once, in lockstep, from the values still in registers

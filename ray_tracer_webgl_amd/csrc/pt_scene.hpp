@@ -107,7 +107,7 @@ struct GridWalk {  // boundary-crossing times, linear cell index, steps left per
 //                      in LDS, slots in global memory / L2, 3 = both in global memory;
 //                4..6  the uniform grid of pt_grid.hpp: 4 = cells and entries staged in LDS,
 //                      5 = cells in LDS, entries in global memory / L2, 6 = both global;
-//                7     no structure and no LDS copy: a list of at most 16 spheres (the reference's
+//                7     no structure, the LDS copy only for per-lane gathers: a list of at most 16 spheres (the reference's
 //                      u_sphere_list[15], static/shader.frag:103) tested group by group from SGPRs.
 //              List-order reads (tail mode, PHASE 3, shading) go to the global copy.
 template <bool SCAN_LDS_, bool HAVE_LDS_, int WALK_>

@@ -1,0 +1,35 @@
+"""Dev tool: one-variable sweeps of the scheduling knobs on config 2's timed launch (grid walk, 64 x 16 spp),
+each point in a fresh child process on the PT_DEV_KNOBS build (ray_tracer_webgl_amd/libptrace_knobs.so)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def child():
+    from ray_tracer_webgl_amd import abi, scenes
+    from ray_tracer_webgl_amd.tracer import PathTracer
+    sc = scenes.config2(1920, 1080, 16, 64, 50)
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    pt = PathTracer(1920, 1080)
+    pt.set_geometry_path(abi.PT_GEOM_GRID)
+    if os.environ.get("SW_CARRY"): pt.set_carry_lanes(int(os.environ["SW_CARRY"]))
+    if os.environ.get("SW_REFILL"): pt.set_refill_min(int(os.environ["SW_REFILL"]))
+    pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(64)
+    ms = []
+    for rep in range(4):
+        pt.reset(); pt.render_passes(64); ms.append(pt.stats().render_kernel_ms)
+    print("%.3f" % min(ms[1:]), flush=True)
+    pt.close()
+
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    child()
+else:
+    lib = os.path.join(ROOT, "ray_tracer_webgl_amd", "libptrace_knobs.so")
+    points = [("base", {})] + [("carry %d" % v, {"SW_CARRY": str(v)}) for v in (6, 8, 10, 16, 20)] + \
+             [("refill_min %d" % v, {"SW_REFILL": str(v)}) for v in (1, 2, 6, 8)] + \
+             [("block %d" % v, {"PT_BVH_BLOCK": str(v)}) for v in (256, 1024)] + \
+             [("chunk %d" % v, {"PT_QUEUE_CHUNK": str(v)}) for v in (128, 256, 1024, 2048)] + \
+             [("long_item %d" % v, {"PT_LONG_ITEM": str(v)}) for v in (0, 48, 1000000)] + [("base again", {})]
+    for name, env in points:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, PT_LIB=lib, **env),
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        print("%-16s %s" % (name, out.stdout.strip() or ("FAILED " + out.stderr[-300:])), flush=True)
