@@ -104,7 +104,20 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       else if constexpr (S::GRID) grid_walk<S, COUNT>(A, p, scan_lane, n_live, cw, gw, h, tally);
       else if constexpr (S::SMALL) small_scan<S>(A, p, scan_lane, h);
       else list_scan<S>(A, p, scan_lane, h);
-      literal_loop<S>(A, p, h);
+      tally.literal(A, p.alive && !fast, scan_lane && h.lit_from < A.n_spheres, p.slab_index);
+      // a REGULAR ray the grid walk hands over whole (it starts far outside the scene and reaches the
+      // grid: pt_grid_walk.hpp) is looked at by the whole wave, 64 spheres at a time, like the rays of
+      // tail mode, where the list is long (the kernels whose entries do not fit the LDS: thousands of
+      // spheres, 0.3 ms per ray through the literal loop; config 5: 2.3e-5 of the rays, 1.5 % of the time)
+      if constexpr (S::GRID && S::WALK != 4) {
+        const bool handed_over = scan_lane && h.lit_from == 0u;
+        const unsigned long long m_h = pt_ballot(handed_over);
+        if (m_h != 0ull) {
+          tail_mode<S>(A, p, m_h, h);
+          if (handed_over) h.lit_from = 0xffffffffu;
+        }
+      }
+      literal_loop<S>(A, p, h); // (irregular rays; list kernels: candidates that did not fit the queue)
     }
     if constexpr (S::TREE) {
       if (coop) cw.carried = false;

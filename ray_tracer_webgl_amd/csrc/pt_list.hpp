@@ -245,8 +245,24 @@ __device__ __forceinline__ void literal_loop(const PtKernelArgs& A, const Path& 
   const V3 o = p.o; const V3 d = p.d; const float a = p.a; const bool alive = p.alive;
   float closest = h.closest; int hit = h.hit; const uint32_t lit_from = h.lit_from;
   const uint32_t n_spheres = A.n_spheres;
-  const bool lit = alive && lit_from < n_spheres;
+  bool lit = alive && lit_from < n_spheres;
   unsigned long long lit_mask = pt_ballot(lit);
+  if (lit_mask != 0ull) {
+    // A ray with a NaN in its origin or direction needs no loop: for EVERY sphere oc or half_b is NaN,
+    // so c or half_b^2 and with it the discriminant are NaN, :153 does not return, both roots are NaN,
+    // and NaN fails all four rejections of :159/:161 whatever closest_so_far holds — each sphere of the
+    // list is accepted in turn.  The loop ends on the LAST sphere with a NaN root.  (Once a path has
+    // left the real numbers — refract() returned vec3(0), :273, and the next hit point is 0 * NaN — it
+    // stays there for the rest of its max_depth segments; in a scene of 10^4 spheres those segments
+    // cost the whole wave 0.3 ms each through the loop below.)
+    const bool nan_ray = lit && (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z);
+    if (nan_ray) {
+      closest = __builtin_nanf("");
+      hit = (int)n_spheres - 1;
+      lit = false;
+    }
+    lit_mask = pt_ballot(lit);
+  }
   if (lit_mask != 0ull) {
     // wave-uniform start: the smallest lit_from of any lane
     uint32_t start = lit ? lit_from : 0xffffffffu;

@@ -251,6 +251,19 @@ struct Tally {
   __device__ __forceinline__ void exact(unsigned long long mask) { if constexpr (COUNT) { n_exact_it++; n_exact_ln += (uint32_t)__popcll(mask); } }
   __device__ __forceinline__ void step() { if constexpr (COUNT) n_steps++; }
   __device__ __forceinline__ void carried(bool c) { if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(c)); }
+  // who takes PHASE 3 (the literal loop over the whole list): irregular rays, and regular ones the walk hands over
+  __device__ __forceinline__ void literal(const PtKernelArgs& A, bool irregular, bool handed_over, uint32_t slab_index) {
+    if constexpr (COUNT) {
+      const unsigned long long mi = pt_ballot(irregular), mh = pt_ballot(handed_over);
+      if ((mi | mh) != 0ull && lane_id() == 0) {
+        atomicAdd(&A.counters[PT_CTR_LITERAL + 0], (unsigned long long)__popcll(mi));
+        atomicAdd(&A.counters[PT_CTR_LITERAL + 1], (unsigned long long)__popcll(mh));
+        atomicAdd(&A.counters[PT_CTR_LITERAL + 2], 1ull); // wave steps that ran the loop
+      }
+      if (irregular) A.counters[PT_CTR_LITERAL + 3] = 1ull + slab_index; // (any one of them: where to look)
+      else if (handed_over) A.counters[PT_CTR_LITERAL + 4] = 1ull + slab_index;
+    }
+  }
   __device__ __forceinline__ void queue_dry() { if constexpr (COUNT) { if (t_wave_dry == 0) t_wave_dry = __builtin_amdgcn_s_memrealtime(); } }
   __device__ __forceinline__ void phase(int k) {
     if constexpr (COUNT) {

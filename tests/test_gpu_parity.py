@@ -953,6 +953,55 @@ def test_grid_kernels_for_scenes_beyond_the_lds(ora):
     t2.close()
 
 
+def _literal_counters(t):
+    """(irregular lane-steps, lane-steps handed over by the grid walk, wave steps that ran PHASE 3) of the last
+    measuring-twin launch (dev interface, include/ptrace_dev.h)."""
+    import ctypes as C
+    ctr = np.zeros(128, np.uint64)
+    t.lib.pt_debug_counters.restype = C.c_long
+    t.lib.pt_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    assert t.lib.pt_debug_counters(t._ctx, ctr.ctypes.data_as(C.c_void_p), 128) == 128
+    return int(ctr[16]), int(ctr[17]), int(ctr[18])
+
+
+def test_far_and_nan_rays_in_a_scene_of_thousands(ora):
+    """What the grid walk cannot take in a 10 001-sphere scene.  (a) Regular rays that start far outside
+    the scene and reach the grid are handed over whole; the kernels whose entries do not fit the LDS
+    look at them wave-wide (64 spheres at a time) instead of running the literal loop.  (b) A ray with
+    a NaN in it is accepted by every sphere in turn (static/shader.frag:153-161 reject nothing that is
+    NaN): the literal loop's answer — the LAST sphere, root NaN — is written down without the loop.
+    Both against the oracle (window) and against the list walk (whole frame), then the counters of
+    the measuring twin say that these rays really came by."""
+    from ray_tracer_webgl_amd.scenes import _lib, _look_at
+    far = scenes.config5(160, 90, 2, 1, 12)
+    _look_at(_lib(), far.params, 160, 90, (900.0, 225.0, 900.0), (0.0, 8.0, 0.0), 3.0, 0.0, 500.0)  # 15x as far, 1/13 the angle; |d|^2 stays below 1e6
+    nan = scenes.config5(96, 54, 2, 1, 6)
+    nan.params.camera_origin[1] = float("nan")
+    zero = scenes.config5(96, 54, 2, 1, 6)
+    for k in range(3):
+        zero.params.horizontal[k] = 0.0
+        zero.params.vertical[k] = 0.0
+        zero.params.lower_left_corner[k] = zero.params.camera_origin[k]  # direction == 0 exactly, then NaN hit points
+    for sc, window, want in ((far, (60, 84, 30, 46), 1), (nan, (40, 56, 20, 30), 0), (zero, (40, 56, 20, 30), 0)):
+        t, got, ref = _check_scene(ora, sc, window=window, geometry_path=abi.PT_GEOM_GRID)
+        st = t.stats()
+        assert st.geometry_path == abi.PT_GEOM_GRID and st.grid_entries * 16 > 160 * 1024  # pt_trace_kernel_grid_cells
+        t2, got2 = render_scene(sc, geometry_path=abi.PT_GEOM_SCALAR)
+        assert_bit_equal(got, got2, "grid walk vs list walk, whole frame")
+        assert t2.stats().segments == st.segments
+        t.reset()
+        t.set_count_work(True)
+        t.render_passes(1)
+        assert_bit_equal(t.accum(), got, "measuring twin")
+        irregular, handed_over, literal_steps = _literal_counters(t)
+        if want == 1:
+            assert handed_over > 1000, (irregular, handed_over)
+        else:
+            assert irregular > 1000, (irregular, handed_over)
+        t.close()
+        t2.close()
+
+
 @pytest.mark.parametrize("path", [abi.PT_GEOM_BVH, abi.PT_GEOM_GRID])
 def test_measuring_twin_equals_the_timed_kernel(ora, path):
     """bench.py's `roofline.executed` tallies come from a DIFFERENT binary than the one it times (the

@@ -26,6 +26,7 @@ def child():
              ("c4lds", scenes.config4(1024, 1024, 64, 8, 50), 8, abi.PT_GEOM_LDS, 2),
              ("c5grid", scenes.config5(1920, 1080, 64, 4, 50), 4, abi.PT_GEOM_GRID, 3),
              ("c5grid16", scenes.config5(1920, 1080, 16, 16, 50), 16, abi.PT_GEOM_GRID, 3),
+             ("c5grid32", scenes.config5(1920, 1080, 32, 8, 50), 8, abi.PT_GEOM_GRID, 3),  # (holds a pixel whose paths leave the real numbers)
              ("default", scenes.default_scene(1280, 702, 25, 8, 16), 16, abi.PT_GEOM_SCALAR, 3),
              ("default1", scenes.default_scene(1280, 702, 1, 8, 1), 1, abi.PT_GEOM_SCALAR, 5),
              ("c4small", scenes.config4(1024, 1024, 64, 8, 50), 8, abi.PT_GEOM_SMALL, 2),

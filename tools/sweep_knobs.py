@@ -7,16 +7,20 @@ sys.path.insert(0, ROOT)
 def child():
     from ray_tracer_webgl_amd import abi, scenes
     from ray_tracer_webgl_amd.tracer import PathTracer
-    sc = scenes.config2(1920, 1080, 16, 64, 50)
+    spp, n = int(os.environ.get("SW_SPP", "16")), int(os.environ.get("SW_PASSES", "64"))
+    if os.environ.get("SW_CONFIG", "config2") == "config5":
+        sc = scenes.config5(1920, 1080, spp, n, 50)
+    else:
+        sc = scenes.config2(1920, 1080, spp, n, 50)
     sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
     pt = PathTracer(1920, 1080)
     pt.set_geometry_path(abi.PT_GEOM_GRID)
     if os.environ.get("SW_CARRY"): pt.set_carry_lanes(int(os.environ["SW_CARRY"]))
     if os.environ.get("SW_REFILL"): pt.set_refill_min(int(os.environ["SW_REFILL"]))
-    pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(64)
+    pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(n)
     ms = []
     for rep in range(4):
-        pt.reset(); pt.render_passes(64); ms.append(pt.stats().render_kernel_ms)
+        pt.reset(); pt.render_passes(n); ms.append(pt.stats().render_kernel_ms)
     print("%.3f" % min(ms[1:]), flush=True)
     pt.close()
 
@@ -29,6 +33,10 @@ else:
              [("block %d" % v, {"PT_BVH_BLOCK": str(v)}) for v in (256, 1024)] + \
              [("chunk %d" % v, {"PT_QUEUE_CHUNK": str(v)}) for v in (128, 256, 1024, 2048)] + \
              [("long_item %d" % v, {"PT_LONG_ITEM": str(v)}) for v in (0, 48, 1000000)] + [("base again", {})]
+    if len(sys.argv) > 1:  # e.g. sweep_knobs.py SW_CONFIG=config5,SW_SPP=16,SW_PASSES=16 PT_QUEUE_CHUNK=32,64,128
+        fixed = dict(kv.split("=") for kv in sys.argv[1].split(","))
+        var, vals = sys.argv[2].split("=")
+        points = [("%s %s" % (var, v), dict(fixed, **{var: v})) for v in vals.split(",")]
     for name, env in points:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, PT_LIB=lib, **env),
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)

@@ -1,6 +1,6 @@
 """Dev tool: when do the waves of a launch start, see the queue dry, and end?  (measuring twin)
 
-    python tools/wave_log.py [ranks] [passes] [spp]
+    python tools/wave_log.py [ranks] [passes] [spp]      (WL_CONFIG=config5: that scene; WL_DECO=1: decorrelated pass times)
 """
 import ctypes as C
 import os
@@ -15,7 +15,9 @@ from ray_tracer_webgl_amd.tracer import PathTracer  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-sc = scenes.config2(1920, 1080, spp, passes, 50)
+sc = (scenes.config5 if os.environ.get("WL_CONFIG") == "config5" else scenes.config2)(1920, 1080, spp, passes, 50)
+if os.environ.get("WL_DECO"):
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
 p = sc.params.copy()
 p.band_rows, p.band_index, p.band_count = ptdist.band_of(0, n, 4)
 pt = PathTracer(1920, 1080)
@@ -57,3 +59,6 @@ print("   " + " ".join("%.1f" % (bins[b] / 0.65536e-3 / 1e9) for b in order if b
 ph = ctr[24:31].astype(np.float64)
 names = ["refill", "camera ray", "set-up + always-tested", "advance / node loops", "leaf + exact", "literal + unpark", "shade"]
 print("  wave-time shares by phase (s_memtime): " + ", ".join("%s %.3f" % (n_, v / ph.sum()) for n_, v in zip(names, ph)))
+lit = ctr[16:21]
+print("  PHASE 3 (literal loop): %d irregular lane-steps, %d handed over by the walk, %d wave steps; last irregular pixel (slab index) %d, last handed-over %d"
+      % (lit[0], lit[1], lit[2], int(lit[3]) - 1, int(lit[4]) - 1))
