@@ -255,7 +255,10 @@ __device__ __forceinline__ void literal_loop(const PtKernelArgs& A, const Path& 
     // left the real numbers — refract() returned vec3(0), :273, and the next hit point is 0 * NaN — it
     // stays there for the rest of its max_depth segments; in a scene of 10^4 spheres those segments
     // cost the whole wave 0.3 ms each through the loop below.)
-    const bool nan_ray = lit && (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z);
+    // The same holds for a direction of exactly zero (what refract() leaves behind): half_b is +-0 or
+    // NaN, |d|^2 is 0, the discriminant +-0 or NaN, and (+-0 -+ 0) / 0 is NaN.
+    const bool nan_ray = lit && (o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z ||
+                                 (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f));
     if (nan_ray) {
       closest = __builtin_nanf("");
       hit = (int)n_spheres - 1;
