@@ -65,10 +65,15 @@ FLOP_PER_SEGMENT_SHADE = 150   # scatter + RNG + camera share
 # (tests/golden/full_frame_digests.json: the single-GPU frame rendered as passes of 16 spp with
 # decorrelated pass times, exactly what the default flags of this script render)
 BENCH_CONFIGS = {
-    "2": {"name": "config2", "width": 1920, "height": 1080, "spp": 1024,
-          "digest": "config2_1920x1080_64x16spp_decorrelated"},
-    "3": {"name": "config3", "width": 3840, "height": 2160, "spp": 4096,
-          "digest": "config3_3840x2160_256x16spp_decorrelated"},
+    "2": {"name": "config2", "scene": "config2", "what": "Shirley cover scene", "width": 1920, "height": 1080, "spp": 1024,
+          "digest": "config2_1920x1080_64x16spp_decorrelated", "cpu_strip": 960},
+    "3": {"name": "config3", "scene": "config3", "what": "Shirley cover scene", "width": 3840, "height": 2160, "spp": 4096,
+          "digest": "config3_3840x2160_256x16spp_decorrelated", "cpu_strip": 960},
+    # the stress configs of BASELINE.json (not the metric's config): the same line for them
+    "4": {"name": "config4", "scene": "config4", "what": "closed room with an emissive sphere", "width": 1024, "height": 1024,
+          "spp": 8192, "digest": None, "cpu_strip": 1024},
+    "5": {"name": "config5", "scene": "config5", "what": "random field + ground", "width": 1920, "height": 1080, "spp": 256,
+          "digest": None, "cpu_strip": 40},
 }
 
 
@@ -181,9 +186,10 @@ def plan_steps(converged_spp, spp_per_pass, passes_per_step, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", default="2", choices=["2", "3", "default"],
+    ap.add_argument("--config", default="2", choices=["2", "3", "4", "5", "default"],
                     help="BASELINE config: 2 = cover scene 1920x1080 1024 spp (the metric's config), 3 = the same at "
-                         "3840x2160 4096 spp, default = the reference's own 1-spp frame loop on State::default")
+                         "3840x2160 4096 spp, 4 = closed room 1024x1024 8192 spp, 5 = 10 000-sphere field 1920x1080 256 spp, "
+                         "default = the reference's own 1-spp frame loop on State::default")
     ap.add_argument("--steps", type=int, default=None, help="default: the config's converged frame (16 / 64)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--steps-per-launch", type=int, default=16)
@@ -202,7 +208,8 @@ def main():
     ap.add_argument("--no-work-count", action="store_true", help="skip the measuring-twin launch (roofline.frac = null)")
     ap.add_argument("--no-first-frame", action="store_true", help="skip the cold first-frame measurement")
     ap.add_argument("--no-weak-series", action="store_true", help="N > 1: skip the weak-scaling point after the main region")
-    ap.add_argument("--cpu-strip", type=int, default=960, help="width of the CPU baseline's column strip")
+    ap.add_argument("--cpu-strip", type=int, default=None,
+                    help="width of the CPU baseline's column strip (default per config: 10-30 s of CPU work)")
     ap.add_argument("--frames", type=int, default=400, help="--config default: frames per timed replay series")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
@@ -269,8 +276,7 @@ def main():
             return ptdist.gather_rows(t.cpu(), p.height, band_rows, rank, world)
         return ptdist.gather_rows(t, p.height, band_rows, rank, world)
 
-    make = scenes.config3 if args.config == "3" else scenes.config2
-    sc = make(width, height, args.spp_per_pass, steps * pps, args.max_depth)
+    sc = getattr(scenes, cfg["scene"])(width, height, args.spp_per_pass, steps * pps, args.max_depth)
     p = sc.params.copy()
     band_rows = args.band_rows
     p.band_rows, p.band_index, p.band_count = ptdist.band_of(rank, world, band_rows)
@@ -421,8 +427,18 @@ def main():
         # algorithmic HBM bytes per pass of the trace kernel: one 16-B slab store per (pixel, pass)
         # item (+ the scene once per launch, 48 B/sphere); the fold kernel's traffic is separate
         hbm_bytes_per_pass = local_pix * 16 + n_sph * 48 / max(ppl, 1)
-        kernel_name = {abi.PT_GEOM_LDS: "pt_trace_kernel", abi.PT_GEOM_SCALAR: "pt_trace_kernel_scalar",
+        kernel_name = {abi.PT_GEOM_LDS: "pt_trace_kernel", abi.PT_GEOM_SCALAR: "pt_trace_kernel_scalar", abi.PT_GEOM_SMALL: "pt_trace_kernel_small",
                        abi.PT_GEOM_BVH: "pt_trace_kernel_bvh", abi.PT_GEOM_GRID: "pt_trace_kernel_grid"}.get(st.geometry_path, "?")
+        # which build of a walk kernel: everything staged in the LDS, the nodes / cell records only, or nothing
+        # (pt_api.hip bind_hierarchy / bind_grid: what fits beside a 1024-thread workgroup's 60 KiB of parked state)
+        lds_room = 163776 - 15 * 4 * 1024
+        if st.geometry_path == abi.PT_GEOM_GRID:
+            cells_b = 4 * int(st.grid_cells[0]) * int(st.grid_cells[1]) * int(st.grid_cells[2])
+            if cells_b + 16 * int(st.grid_entries) > lds_room:
+                kernel_name += "_cells" if cells_b <= lds_room else "_gmem"
+        elif st.geometry_path == abi.PT_GEOM_BVH:
+            if (2 * int(st.bvh_nodes) + int(st.bvh_slots)) * 16 > lds_room:
+                kernel_name += "_nodes" if int(st.bvh_nodes) * 16 <= lds_room else "_gmem"
         walk = st.geometry_path in (abi.PT_GEOM_BVH, abi.PT_GEOM_GRID)
         chosen_path = st.geometry_path
 
@@ -578,7 +594,7 @@ def main():
             flags, native = build_native_oracle()
             from oracle import oracle
 
-            strip = min(args.cpu_strip, p.width)
+            strip = min(args.cpu_strip or cfg["cpu_strip"], p.width)
             x0 = (p.width - strip) // 2
             cp = sc.params.copy()
             cp.samples_per_pixel = spp_step  # one step's worth of samples in one pass (the longest streams)
@@ -611,8 +627,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: Shirley cover scene (%d spheres), %dx%d, %d bounces, %d spp/step (%d passes x %d spp) x %d steps = %d spp"
-                            % (cfg["name"], n_sph, p.width, p.height, args.max_depth, spp_step, pps, args.spp_per_pass, steps, spp_step * steps),
+                "workload": "%s: %s (%d spheres), %dx%d, %d bounces, %d spp/step (%d passes x %d spp) x %d steps = %d spp"
+                            % (cfg["name"], cfg["what"], n_sph, p.width, p.height, args.max_depth, spp_step, pps, args.spp_per_pass, steps, spp_step * steps),
                 "partition": "%d rank(s), interleaved %d-row bands, one all_gather at the end of the timed region%s"
                              % (world, band_rows, "; per-GPU work fixed: 1/%d of the rows x %d passes per step" % (world, pps)
                                 if weak else ("; the same frame for every N" if world > 1 else "")),

@@ -236,3 +236,20 @@ def test_bench_single_gpu_line_matches_the_committed_digest():
     ex = d["roofline"]["executed"]
     assert ex and ex["twin_segments_equal_timed_kernel"] is True
     assert d["roofline"]["frac"] and 0 < d["roofline"]["frac"] <= 1
+
+
+@pytest.mark.parametrize("config,kernels", [("4", ("pt_trace_kernel_small", "pt_trace_kernel", "pt_trace_kernel_scalar")),
+                                            ("5", ("pt_trace_kernel_grid_cells", "pt_trace_kernel_bvh_nodes"))])
+def test_bench_lines_of_the_stress_configs(config, kernels):
+    """`bench.py --config 4 / 5`: BASELINE's closed room and 10 000-sphere field through the same line
+    (roofline + cpu_baseline), here at a reduced size; the kernel named is one this scene can get
+    (PT_GEOM_AUTO measures on a small frame here, so which of them wins is not asserted)."""
+    d = _bench("--config", config, "--width", "192", "--height", "108", "--steps", "2", "--warmup", "1", "--cpu-strip", "8")
+    assert ("config" + config) in d["config"]["workload"] and d["n_gpus"] == 1 and d["value"] > 0
+    r = d["roofline"]
+    assert r["kernel"] in kernels, r["kernel"]
+    assert d["cpu_baseline"]["value"] > 0 and d["gather_matches_single_gpu"] is None
+    if config == "5":
+        assert d["list_walk"]["roofline_frac"] > 0
+    if r["kernel"] != "pt_trace_kernel_bvh_nodes":  # (that build has no measuring twin)
+        assert r["frac"] and 0 < r["frac"] <= 1
