@@ -71,9 +71,9 @@ BENCH_CONFIGS = {
           "digest": "config3_3840x2160_256x16spp_decorrelated", "cpu_strip": 960},
     # the stress configs of BASELINE.json (not the metric's config): the same line for them
     "4": {"name": "config4", "scene": "config4", "what": "closed room with an emissive sphere", "width": 1024, "height": 1024,
-          "spp": 8192, "digest": None, "cpu_strip": 1024},
+          "spp": 8192, "digest": "config4_1024x1024_512x16spp_decorrelated", "cpu_strip": 1024},
     "5": {"name": "config5", "scene": "config5", "what": "random field + ground", "width": 1920, "height": 1080, "spp": 256,
-          "digest": None, "cpu_strip": 40},
+          "digest": "config5_1920x1080_16x16spp_decorrelated", "cpu_strip": 40},
 }
 
 

@@ -40,6 +40,15 @@ t, a = render_scene(sc, passes_per_launch=64)
 out["config3_3840x2160_256x16spp_decorrelated"] = {
     "sha256": hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest(),
     "segments": int(t.stats().segments)}
+t.close()
+# the stress configs as bench.py --config 4 / --config 5 render them (16-spp passes, decorrelated pass times)
+for key, sc, ppl in (("config4_1024x1024_512x16spp_decorrelated", scenes.config4(1024, 1024, 16, 512, 50), 64),
+                     ("config5_1920x1080_16x16spp_decorrelated", scenes.config5(1920, 1080, 16, 16, 50), 16)):
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    t, a = render_scene(sc, passes_per_launch=ppl)
+    out[key] = {"sha256": hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest(),
+                "segments": int(t.stats().segments)}
+    t.close()
 path = os.path.join(HERE, "full_frame_digests.json")
 if os.environ.get("GRAFT_REPO_ROOT"):
     path = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "full_frame_digests.json")

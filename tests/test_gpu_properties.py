@@ -253,3 +253,15 @@ def test_bench_lines_of_the_stress_configs(config, kernels):
         assert d["list_walk"]["roofline_frac"] > 0
     if r["kernel"] != "pt_trace_kernel_bvh_nodes":  # (that build has no measuring twin)
         assert r["frac"] and 0 < r["frac"] <= 1
+
+
+@pytest.mark.parametrize("config", ["4", "5"])
+def test_bench_stress_config_frames_match_the_committed_digests(config):
+    """The full frames `bench.py --config 4 / 5` time (8192 spp of the closed room, 256 spp of the
+    10 001-sphere field) hash to tests/golden/full_frame_digests.json — drift guards of the HIP path
+    across rounds (their pixels are pinned by the oracle windows of test_config4_room_8192spp
+    and test_config5_field_256spp), and the frame an N > 1 run of these configs would have to gather."""
+    d = _bench("--config", config, "--no-cpu-baseline", "--no-list-walk", "--no-work-count", "--no-first-frame", "--warmup", "1")
+    assert d["gather_matches_single_gpu"] is True, d["gather_check"]
+    assert d["gather_check"]["segments_match"] is True
+    assert d["converged_frame_spp"] == {"4": 8192, "5": 256}[config]
