@@ -50,6 +50,7 @@ struct Opt {
       t_shade = 24;
   int node_burst = 8;    // node iterations per scheduler trip at most
   int eager = 0;         // mode 0: leaf + exact rounds (to empty queues) after every `eager` node iterations
+  int block = 0;         // mode 2: a lane with candidates waits (no cell steps, no leaf rounds) until `block` lanes wait or nobody else can move; 0 = evaluate after every leaf round
   int carry = 0;         // mode 0: stop walking when fewer than `carry` lanes walk; they resume in the next wave step
   int outlier_exact = 0;
   int cell_x100 = 100;   // mode 2: grid cell edge = cell_x100 / 100 x the heuristic edge
@@ -628,13 +629,13 @@ struct Sim {
           int mv = 0;
           for (int i = 0; i < 64; i++) {
             GLane& g = Gs[i];
-            if (!g.active || g.pend_count) continue;
+            if (!g.active || g.pend_count || (op.block && !cand[i].empty())) continue;
             mv++;
           }
           if (!mv) break;
           for (int i = 0; i < 64; i++) {
             GLane& g = Gs[i];
-            if (!g.active || g.pend_count) continue;
+            if (!g.active || g.pend_count || (op.block && !cand[i].empty())) continue;
             // stand on cell: look at it, then step
             const size_t c = ((size_t)g.cell[2] * G.n[1] + g.cell[1]) * G.n[0] + g.cell[0];
             cells_visited++; L[i].nodes_this_seg++;
@@ -648,20 +649,27 @@ struct Sim {
           }
           ph_dda.iters++; ph_dda.lanes += mv; cost += C_DDA;
         }
-        int busy = 0; for (int i = 0; i < 64; i++) if (Gs[i].pend_count) busy++;
-        if (!busy) break;
+        int busy = 0; for (int i = 0; i < 64; i++) if (Gs[i].pend_count && !(op.block && !cand[i].empty())) busy++;
+        if (!busy) {
+          int nb = 0; for (int i = 0; i < 64; i++) if (!cand[i].empty()) nb++;
+          if (!nb) break;
+          drain_all(); // nobody else can move: the waiting lanes are served
+          for (int i = 0; i < 64; i++) if (Gs[i].active && !Gs[i].pend_count && L[i].closest <= Gs[i].t_exit) Gs[i].active = false;
+          continue;
+        }
         // one leaf round: up to four entries of the pending cell
         for (int i = 0; i < 64; i++) {
           GLane& g = Gs[i];
-          if (!g.pend_count) continue;
+          if (!g.pend_count || (op.block && !cand[i].empty())) continue;
           leaf_visits++;
           uint32_t k = std::min(4u, g.pend_count);
           for (uint32_t j = 0; j < k; j++) if (test_g(L[i], &G.slots[4 * (g.pend_start + j)])) cand[i].push_back(g.pend_start + j);
           g.pend_start += k; g.pend_count -= k;
         }
         ph_leaf.iters++; ph_leaf.lanes += busy; cost += C_LEAF;
-        drain_all();
-        for (int i = 0; i < 64; i++) if (Gs[i].active && !Gs[i].pend_count && L[i].closest <= Gs[i].t_exit) Gs[i].active = false;
+        if (op.block) { int nb = 0; for (int i = 0; i < 64; i++) if (!cand[i].empty()) nb++; if (nb >= op.block) drain_all(); }
+        else drain_all();
+        for (int i = 0; i < 64; i++) if (cand[i].empty() && Gs[i].active && !Gs[i].pend_count && L[i].closest <= Gs[i].t_exit) Gs[i].active = false;
       }
       int n = 0;
       for (int i = 0; i < 64; i++) if (L[i].alive) {
@@ -715,7 +723,7 @@ int main(int argc, char** argv) {
       {"fifo", &S.op.leaf_fifo}, {"spp", &S.op.spp}, {"passes", &S.op.passes}, {"chunk", &S.op.chunk},
       {"t_cam", &S.op.t_cam}, {"t_node", &S.op.t_node}, {"t_node_exit", &S.op.t_node_exit}, {"t_leaf", &S.op.t_leaf},
       {"t_leaf_exit", &S.op.t_leaf_exit}, {"t_exact", &S.op.t_exact}, {"t_exact_exit", &S.op.t_exact_exit},
-      {"t_shade", &S.op.t_shade}, {"burst", &S.op.node_burst}, {"outlier_exact", &S.op.outlier_exact}, {"eager", &S.op.eager}, {"cell", &S.op.cell_x100}, {"big", &S.op.big_x100}, {"carry", &S.op.carry}};
+      {"t_shade", &S.op.t_shade}, {"burst", &S.op.node_burst}, {"outlier_exact", &S.op.outlier_exact}, {"eager", &S.op.eager}, {"cell", &S.op.cell_x100}, {"big", &S.op.big_x100}, {"carry", &S.op.carry}, {"block", &S.op.block}};
   for (int i = 2; i < argc; i++) {
     char* eq = strchr(argv[i], '=');
     if (!eq) continue;
