@@ -346,6 +346,25 @@ def test_irregular_scene_and_rays_take_the_literal_path(ora):
     sc.params.camera_origin[0] = 3e15  # finite but outside the regular range
     t, got, ref = _check_scene(ora, sc)
     t.close()
+    # NaN and zero-direction rays are answered without the loop (every sphere accepts a NaN root: the last
+    # one wins) — also in a scene whose spheres are not finite themselves
+    for kind in ("nan", "zero"):
+        sc = scenes.default_scene(40, 24, spp=2, max_depth=5)
+        sp = np.concatenate([sc.spheres, sc.spheres[:3]])
+        sp[9]["center"] = (np.float32("inf"), 0.0, 0.0)
+        sp[10]["radius"] = np.float32("nan")
+        sp[11]["center"] = (np.float32("nan"), np.float32("-inf"), 1e30)
+        sp["uuid"] = np.arange(len(sp))
+        sc.spheres = sp
+        if kind == "nan":
+            sc.params.camera_origin[2] = float("nan")
+        else:
+            for k in range(3):
+                sc.params.horizontal[k] = 0.0
+                sc.params.vertical[k] = 0.0
+                sc.params.lower_left_corner[k] = sc.params.camera_origin[k]
+        t, got, ref = _check_scene(ora, sc)
+        t.close()
 
 
 def test_passes_batched_equals_separate_launches(ora):
