@@ -972,6 +972,22 @@ def test_grid_kernels_for_scenes_beyond_the_lds(ora):
     t2.close()
 
 
+def test_grid_in_global_memory(ora):
+    """60 001 spheres: 31 000 cell records (0.12 MB) and 0.13 M entries (2 MB) — neither fits the LDS, so
+    pt_trace_kernel_grid_gmem reads both from global memory / L2.  Window-checked against the oracle,
+    whole frame against the list walk."""
+    sc = scenes.config5(128, 72, 2, 1, 12, n=60000)
+    t, got, ref = _check_scene(ora, sc, window=(56, 72, 30, 40), geometry_path=abi.PT_GEOM_GRID)
+    st = t.stats()
+    assert st.geometry_path == abi.PT_GEOM_GRID
+    assert st.grid_cells[0] * st.grid_cells[1] * st.grid_cells[2] * 4 > 102336  # more cell records than fit beside the parked state
+    t2, got2 = render_scene(sc, geometry_path=abi.PT_GEOM_SCALAR)
+    assert_bit_equal(got, got2, "grid walk (global memory) vs list walk, whole frame")
+    assert t2.stats().segments == st.segments
+    t.close()
+    t2.close()
+
+
 def _literal_counters(t):
     """(irregular lane-steps, lane-steps handed over by the grid walk, wave steps that ran PHASE 3) of the last
     measuring-twin launch (dev interface, include/ptrace_dev.h)."""
