@@ -32,7 +32,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   float closest = h.closest; int hit = h.hit; uint32_t lit_from = h.lit_from;
   bool carried = cw.carried; uint32_t hit_pos = cw.hit_pos;
   float tmx = w.tmx, tmy = w.tmy, tmz = w.tmz, t_exit = w.t_exit;
-  uint32_t cell = w.cell, rem = w.rem, pend = w.pend; bool gactive = w.gactive;
+  uint32_t cell = w.cell, rem = w.rem, pend = w.pend; // rem == 0: this lane's walk is over (or has not begun)
   const uint32_t n_cell_entries = A.n_tree_slots;
   const bool fresh = scan_lane && !carried;
   const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
@@ -109,7 +109,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   const int sdz = posz ? gnx * gny : -(gnx * gny);
 
   // entry: where does the half-line meet the grid's box?
-  if (!carried) { gactive = false; pend = 0u; }
+  if (!carried) { rem = 0u; pend = 0u; }
   if (pt_ballot(fresh) != 0ull) {
     // near rays (|o - c0| + s0 <= d_near, tested on squares: grid_r2_near = (0.9999 d_near - s0)^2):
     // every registered box lies inside [lo, hi] (delta_g is part of it); the host has widened
@@ -140,7 +140,6 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       enter = false;
     }
     if (enter) {
-      gactive = true;
       // the cell that holds the entry point (clamped: rounding may put it a hair outside)
       const float glx = K.grid_lo[0], gly = K.grid_lo[1], glz = K.grid_lo[2];
       const float ghx = K.grid_h[0], ghy = K.grid_h[1], ghz = K.grid_h[2];
@@ -174,8 +173,9 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     // advance: a lane without a cell under test looks at the cell it stands in, notes its
     // exit time, and steps on; it leaves this loop with a non-empty cell or with its walk over
     for (;;) {
-      const bool mv = gactive && (pend >> 24) == 0u;
-      const unsigned long long m_mv = pt_ballot(mv);
+      // (ballots of single compares, joined as masks: a ballot of `a && b` goes through a VGPR)
+      const bool mv = rem != 0u && pend < 0x1000000u;
+      const unsigned long long m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
       if (m_mv == 0ull) break;
       tally.walk(m_mv);
       if (mv) {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
         // the walk is over when it leaves the grid — or, on an empty cell, when the closest
         // root so far lies strictly before this cell's exit (a non-empty cell asks again
         // after its entries have been tested)
-        if (out || ((rec >> 24) == 0u && closest < tmin)) gactive = false;
+        if (out || ((rec >> 24) == 0u && closest < tmin)) rem = 0u;
       }
     }
     tally.phase(3);
@@ -223,11 +223,11 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       }
       exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
       // the cell is done: can anything registered only in later cells still win?
-      if (has && (pend >> 24) == 0u && closest < t_exit) gactive = false;
+      if (has && (pend >> 24) == 0u && closest < t_exit) rem = 0u;
     }
     tally.phase(4);
     walk_iters++;
-    const unsigned long long m_on = pt_ballot(gactive || (pend >> 24) != 0u);
+    const unsigned long long m_on = pt_ballot(rem != 0u) | pt_ballot(pend >= 0x1000000u);
     if (m_on == 0ull) break;
     const uint32_t n_on = (uint32_t)__popcll(m_on);
     // carry the stragglers: the longer this step's walk has run, the more lanes may be left behind
@@ -236,13 +236,13 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     if (walk_iters >= 2u && A.carry_lanes != 0u && n_on < A.carry_lanes + 4u * (walk_iters - 2u) &&
         2u * n_on < (uint32_t)n_live) break;
   }
-  carried = gactive || (pend >> 24) != 0u;
+  carried = rem != 0u || pend >= 0x1000000u;
   tally.carried(carried);
   if (hit_pos != 0xffffffffu) hit = 0; // a hit; shading reads the slot's own copies (index not needed)
   h.closest = closest; h.hit = hit; h.lit_from = lit_from;
   cw.carried = carried; cw.hit_pos = hit_pos;
   w.tmx = tmx; w.tmy = tmy; w.tmz = tmz; w.t_exit = t_exit;
-  w.cell = cell; w.rem = rem; w.pend = pend; w.gactive = gactive;
+  w.cell = cell; w.rem = rem; w.pend = pend;
 }
 
 } // namespace ptk

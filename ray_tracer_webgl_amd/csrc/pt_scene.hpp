@@ -89,7 +89,6 @@ struct GridWalk {  // boundary-crossing times, linear cell index, steps left per
                    // the cell being tested (first untested entry | entries left << 24), its exit time
   float tmx = 0.f, tmy = 0.f, tmz = 0.f, t_exit = 0.f;
   uint32_t cell = 0, rem = 0, pend = 0;
-  bool gactive = false;
 };
 
 // ---- scene data: which memory each kind of read goes to ------------------------------------------
