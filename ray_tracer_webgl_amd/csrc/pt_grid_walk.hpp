@@ -172,13 +172,11 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   for (;;) {
     // advance: a lane without a cell under test looks at the cell it stands in, notes its
     // exit time, and steps on; it leaves this loop with a non-empty cell or with its walk over
-    for (;;) {
-      // (ballots of single compares, joined as masks: a ballot of `a && b` goes through a VGPR)
-      const bool mv = rem != 0u && pend < 0x1000000u;
-      const unsigned long long m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
-      if (m_mv == 0ull) break;
+    // (ballots of single compares, joined as masks: a ballot of `a && b` goes through a VGPR)
+    unsigned long long m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
+    while (m_mv != 0ull) {
       tally.walk(m_mv);
-      if (mv) {
+      if (rem != 0u && pend < 0x1000000u) {
         const uint32_t rec = S::cell_at(A, cell);
         const float tmin = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
         const bool isx = tmx == tmin;
@@ -196,8 +194,9 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
         // the walk is over when it leaves the grid — or, on an empty cell, when the closest
         // root so far lies strictly before this cell's exit (a non-empty cell asks again
         // after its entries have been tested)
-        if (out || ((rec >> 24) == 0u && closest < tmin)) rem = 0u;
+        rem = (out || ((rec >> 24) == 0u && closest < tmin)) ? 0u : rem;
       }
+      m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
     }
     tally.phase(3);
     const bool has = (pend >> 24) != 0u;
