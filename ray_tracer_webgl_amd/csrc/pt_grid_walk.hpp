@@ -42,9 +42,8 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   // all lanes in lockstep: max-over-lanes(popcount) ~ 1-2 evaluations per group
   auto exact_group = [&](uint32_t base, uint32_t& mask, float hb0, float hb1, float hb2, float hb3, float ds0, float ds1,
                          float ds2, float ds3) {
-    for (;;) {
-      const unsigned long long m_x = pt_ballot(mask != 0u);
-      if (m_x == 0ull) break;
+    // (loops on a ballot are written with the ballot as the loop condition: a wave-uniform branch on SCC)
+    for (unsigned long long m_x = pt_ballot(mask != 0u); m_x != 0ull; m_x = pt_ballot(mask != 0u)) {
       tally.exact(m_x);
       if (mask != 0u) {
         const uint32_t k = (uint32_t)__builtin_ctz(mask);
