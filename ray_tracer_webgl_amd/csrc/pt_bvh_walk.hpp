@@ -65,9 +65,8 @@ __device__ __forceinline__ void bvh_walk(const PtKernelArgs& A, const Path& p, b
   };
   // pops and evaluates queued candidates while more than `keep` are queued (lockstep)
   auto drain_to = [&](uint32_t keep) {
-    for (;;) {
-      const unsigned long long m_q = pt_ballot(q_cnt > keep);
-      if (m_q == 0ull) break;
+    // (the ballot is the loop condition: a wave-uniform branch on SCC, see pt_grid_walk.hpp)
+    for (unsigned long long m_q = pt_ballot(q_cnt > keep); m_q != 0ull; m_q = pt_ballot(q_cnt > keep)) {
       tally.exact(m_q);
       if (q_cnt > keep) {
         const uint32_t pp = q0 & 0xffffu;
