@@ -66,7 +66,11 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     }
   };
   // the literal test passes (:153) and the sphere is not behind the ray
-  auto passes = [](float hb, float cc, float ds) -> bool { return !(ds < 0.0f) && !(cc > 0.0f && hb >= 0.0f); };
+  // ... as ONE bit: sign-bit arithmetic instead of three compares.  `ds + 0` has its sign bit clear iff
+  // !(ds < 0) (a -0 from underflow becomes +0); a set sign bit in c or half_b means "not provably behind"
+  // (c >= +0 and half_b >= +0 is: discriminant <= half_b^2, both roots <= 0 < MIN_T).  Regular rays only
+  // (no NaN).  A -0 in c or half_b merely keeps a candidate the float compares would have dropped.
+  auto pass_bit = [](float hb, float cc, float ds) -> uint32_t { return ((f2u(cc) | f2u(hb)) & ~f2u(ds + 0.0f)) >> 31; };
 
   // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is
   // padded with entries that never pass); carried lanes have done this
@@ -89,8 +93,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
       uint32_t mask = 0u;
       if (fresh)
-        mask = (passes(hb0, cc0, ds0) ? 1u : 0u) | (passes(hb1, cc1, ds1) ? 2u : 0u) |
-               (passes(hb2, cc2, ds2) ? 4u : 0u) | (passes(hb3, cc3, ds3) ? 8u : 0u);
+        mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
       exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
     }
   }
@@ -214,8 +217,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       float hb3, cc3, ds3; sphere_test(o, d, a, g3, hb3, cc3, ds3);
       uint32_t mask = 0u;
       if (has) {
-        mask = (passes(hb0, cc0, ds0) ? 1u : 0u) | (passes(hb1, cc1, ds1) ? 2u : 0u) |
-               (passes(hb2, cc2, ds2) ? 4u : 0u) | (passes(hb3, cc3, ds3) ? 8u : 0u);
+        mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
         mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
         pend = left > 4u ? (base + 4u) | ((left - 4u) << 24) : 0u;
       }
