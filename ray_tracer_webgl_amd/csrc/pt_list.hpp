@@ -203,7 +203,9 @@ __device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p,
   const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
   const uint32_t a_guard = hit_root_guard(a);
   const_f4v* c_geom = (const_f4v*)A.geom;
-  auto passes = [](float hb, float cc, float ds) -> bool { return !(ds < 0.0f) && !(cc > 0.0f && hb >= 0.0f); };
+  // the candidate test as ONE bit of sign arithmetic (pt_grid_walk.hpp: `ds + 0` has a clear sign bit iff
+  // !(ds < 0); a set sign bit in c or half_b means "not provably behind"; regular rays only)
+  auto pass_bit = [](float hb, float cc, float ds) -> uint32_t { return ((f2u(cc) | f2u(hb)) & ~f2u(ds + 0.0f)) >> 31; };
 #pragma unroll
   for (uint32_t g = 0; g < 4u; g++) {
     const uint32_t base = 4u * g;
@@ -215,8 +217,7 @@ __device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p,
       float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
       uint32_t mask = 0u;
       if (scan_lane) {
-        mask = (passes(hb0, cc0, ds0) ? 1u : 0u) | (passes(hb1, cc1, ds1) ? 2u : 0u) |
-               (passes(hb2, cc2, ds2) ? 4u : 0u) | (passes(hb3, cc3, ds3) ? 8u : 0u);
+        mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
         const uint32_t left = n_spheres - base; // >= 1, wave-uniform
         mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
       }
