@@ -741,9 +741,7 @@ static int fill_uniforms(pt_ctx* c, uint32_t n_passes, PtKernelArgs& A) {
   A.coop_max_live = 16;
   A.carry_lanes = c->carry_lanes;
   A.refill_min = c->refill_min;
-  A.long_item_segments = 6u * (uint32_t)p.samples_per_pixel;
 #ifdef PT_DEV_KNOBS // A/B builds only (tools/sweep_knobs.py); the product reads no environment
-  if (const char* e = getenv("PT_LONG_ITEM")) A.long_item_segments = (uint32_t)atoi(e);
   if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
 #endif
   // cost feedback for the next launch's tile order: one atomicMax per item of pass 0.  A launch of one

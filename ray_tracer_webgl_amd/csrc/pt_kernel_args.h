@@ -73,7 +73,6 @@ struct PtKernelArgs {
   float grid_lo_n[3], grid_hi_n[3];  // [lo, hi] widened by 1e-6 d_near: the entry slab test of those rays
   uint32_t lds_scene_bytes;        // dynamic LDS taken by the staged scene; the parked path state follows
   unsigned long long* wave_log;    // COUNT twins only (NULL otherwise): per wave {start, queue dry, end} in 100 MHz ticks
-  uint32_t long_item_segments;     // waves holding an item older than this get issue priority (6 x spp: ~1.6x the mean item)
   uint32_t refill_min;             // lanes that must be waiting for an item before a busy wave runs the refill code
   uint32_t carry_lanes;            // the walk moves on when fewer lanes than this (and less than half) still walk
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv

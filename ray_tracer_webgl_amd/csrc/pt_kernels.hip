@@ -87,11 +87,6 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     if (!cw.carried) cw.hit_pos = 0xffffffffu;
     const bool fast = regular_ray(A, p);
     const int n_live = (int)__popcll(live);
-    // A launch cannot end before its longest (pixel, pass) stream has run its serial course,
-    // so waves carrying a long-running item get issue priority: their iterations complete
-    // sooner at no cost in total throughput (the SIMD arbitrates by priority, then age).
-    if (pt_ballot(p.alive && p.item_segs > A.long_item_segments) != 0ull) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
     if constexpr (S::TREE) park_store(A, p);
     const bool coop = (n_live <= (int)A.coop_max_live) && (pt_ballot(p.alive && !fast) == 0ull) &&
                       (pt_ballot(cw.carried) == 0ull);

@@ -32,7 +32,7 @@ else:
              [("refill_min %d" % v, {"SW_REFILL": str(v)}) for v in (1, 2, 6, 8)] + \
              [("block %d" % v, {"PT_BVH_BLOCK": str(v)}) for v in (256, 1024)] + \
              [("chunk %d" % v, {"PT_QUEUE_CHUNK": str(v)}) for v in (128, 256, 1024, 2048)] + \
-             [("long_item %d" % v, {"PT_LONG_ITEM": str(v)}) for v in (0, 48, 1000000)] + [("base again", {})]
+             [("base again", {})]
     if len(sys.argv) > 1:  # e.g. sweep_knobs.py SW_CONFIG=config5,SW_SPP=16,SW_PASSES=16 PT_QUEUE_CHUNK=32,64,128
         fixed = dict(kv.split("=") for kv in sys.argv[1].split(","))
         var, vals = sys.argv[2].split("=")
