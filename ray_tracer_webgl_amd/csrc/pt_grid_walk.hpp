@@ -171,6 +171,8 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
 
   tally.phase(2);
   uint32_t walk_iters = 0;
+  const uint32_t carry_base = A.carry_lanes, carry_slope = A.carry_lanes != 0u ? 4u : 0u; // (0: nobody is left behind)
+  const uint32_t half_live = ((uint32_t)n_live + 1u) >> 1;
   for (;;) {
     // advance: a lane without a cell under test looks at the cell it stands in, notes its
     // exit time, and steps on; it leaves this loop with a non-empty cell or with its walk over
@@ -227,14 +229,17 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     }
     tally.phase(4);
     walk_iters++;
-    const unsigned long long m_on = pt_ballot(rem != 0u) | pt_ballot(pend >= 0x1000000u);
-    if (m_on == 0ull) break;
-    const uint32_t n_on = (uint32_t)__popcll(m_on);
-    // carry the stragglers: the longer this step's walk has run, the more lanes may be left behind
-    // (a long walk means a scene of long walks, where waiting for the last quarter of the lanes costs
-    // more than shading at three quarters; short walks never get past the base threshold)
-    if (walk_iters >= 2u && A.carry_lanes != 0u && n_on < A.carry_lanes + 4u * (walk_iters - 2u) &&
-        2u * n_on < (uint32_t)n_live) break;
+    const uint32_t n_on = (uint32_t)__popcll(pt_ballot(rem != 0u) | pt_ballot(pend >= 0x1000000u));
+    // The loop ends when nobody walks any more — or with a few stragglers left, which are carried: the
+    // longer this step's walk has run, the more lanes may be left behind (a long walk means a scene of
+    // long walks, where waiting for the last quarter of the lanes costs more than shading at three
+    // quarters; short walks never get past the base threshold).  ONE scalar compare: `n_on < lim` with
+    // lim = max(1, min(carry_lanes + 4 (trips - 2), ceil(n_live / 2))) from the second trip on, 1 before
+    // (conditions joined with && would be materialised as lane masks, a dozen scalar instructions per trip).
+    const int t = (int)walk_iters - 2;
+    const uint32_t thr = t >= 0 ? carry_base + carry_slope * (uint32_t)t : 0u;
+    const uint32_t lim = thr < half_live ? thr : half_live;
+    if (n_on < (lim > 1u ? lim : 1u)) break;
   }
   carried = rem != 0u || pend >= 0x1000000u;
   tally.carried(carried);
