@@ -97,7 +97,8 @@ template <bool COUNT>
 __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q, const PixelDiv& pd, Tally<COUNT>& tally) {
   karg_t& K = *kargs();
   // (local copies, written back at the end: see pt_grid_walk.hpp)
-  bool alive = p.alive, exhausted = p.exhausted, new_path = p.new_path;
+  bool alive = p.alive, new_path = p.new_path;
+  bool dry = q.dry; // wave-uniform: a reservation came back empty, so no lane of this wave will get another item
   uint32_t slab_index = p.slab_index, item_tile = p.item_tile, item_segs = p.item_segs;
   int sample = p.sample; float seed = p.seed, st_s = p.st_s, st_t = p.st_t; V3 sum = p.sum;
   uint32_t pool_next = q.pool_next, pool_end = q.pool_end, refill_waited = q.refill_waited;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
   // the first trip makes the compiler peel that trip off, i.e. emit the whole item decode twice)
   bool dealt = false, put_off = false;
   for (;;) {
-    bool need = !alive && !exhausted;
+    bool need = !alive && !dry;
     unsigned long long mask = pt_ballot(need);
     if (mask == 0ull) break;
     // ... but not for long: with long items the next lane may be hundreds of steps away
@@ -136,7 +137,7 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
       if (base >= (unsigned long long)A.n_items) { // queue dry: these lanes are done
         tally.queue_dry();
-        if (need) exhausted = true;
+        dry = true;
         need = false;  // nothing to deal in this trip; the loop ends at its next test
       } else {
         pool_next = (uint32_t)base;
@@ -209,12 +210,12 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     }
   }
   refill_waited = (dealt ? 0u : refill_waited) + (put_off ? 1u : 0u);
-  p.alive = alive; p.exhausted = exhausted; p.new_path = new_path;
+  p.alive = alive; p.new_path = new_path;
   p.slab_index = slab_index; p.item_tile = item_tile; p.item_segs = item_segs;
   p.sample = sample; p.seed = seed; p.st_s = st_s; p.st_t = st_t; p.sum = sum;
   q.pool_next = pool_next; q.pool_end = pool_end; q.refill_waited = refill_waited;
   q.pool_tp0 = pool_tp0; q.pool_split = pool_split; q.pool_tile0 = pool_tile0; q.pool_tile1 = pool_tile1;
-  q.round = q_round;
+  q.round = q_round; q.dry = dry;
 }
 
 } // namespace ptk

@@ -42,7 +42,6 @@ __device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t m, uint32_t s1, 
 // ---- per-lane path state: one (pixel, pass) stream of static/shader.frag:360-383 ----------------
 struct Path {
   bool alive = false;     // lane holds a live ray
-  bool exhausted = false; // queue returned "no more items" to this lane
   bool new_path = false;  // lane must generate its next camera ray before the next scan
   uint32_t slab_index = 0;
   uint32_t item_tile = 0xffffffffu, item_segs = 0; // cost feedback for the next launch's tile order
@@ -59,6 +58,7 @@ struct Queue {
   uint32_t refill_waited = 0;            // steps the waiting lanes have been put off
   uint32_t pool_tp0 = 0, pool_split = 0, pool_tile0 = 0, pool_tile1 = 0;  // the reservation's tile(s)
   uint32_t round = 0;                    // static dealing (A.queue_static): reservations this wave has taken
+  bool dry = false;                      // a reservation came back empty: this wave gets no more items
 };
 
 // ---- the closest hit of the current segment (hit_world's HitRecord, reduced to what shading needs) --
