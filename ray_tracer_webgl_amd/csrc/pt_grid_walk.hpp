@@ -91,9 +91,8 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       float hb1, cc1, ds1; sphere_test(o, d, a, e1, hb1, cc1, ds1);
       float hb2, cc2, ds2; sphere_test(o, d, a, e2, hb2, cc2, ds2);
       float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
-      uint32_t mask = 0u;
-      if (fresh)
-        mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
+      uint32_t mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
+      mask = fresh ? mask : 0u;
       exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
     }
   }
@@ -217,15 +216,14 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       float hb1, cc1, ds1; sphere_test(o, d, a, g1, hb1, cc1, ds1);
       float hb2, cc2, ds2; sphere_test(o, d, a, g2, hb2, cc2, ds2);
       float hb3, cc3, ds3; sphere_test(o, d, a, g3, hb3, cc3, ds3);
-      uint32_t mask = 0u;
-      if (has) {
-        mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
-        mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
-        pend = left > 4u ? (base + 4u) | ((left - 4u) << 24) : 0u;
-      }
+      // (no `if (has)` around this: a lane without a cell under test has left == 0, so its mask is empty and
+      // its pend becomes 0 — which is all that `pend < 2^24` meant for it)
+      uint32_t mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
+      mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
+      pend = left > 4u ? (base + 4u) | ((left - 4u) << 24) : 0u;
       exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
       // the cell is done: can anything registered only in later cells still win?
-      if (has && (pend >> 24) == 0u && closest < t_exit) rem = 0u;
+      rem = (has && pend < 0x1000000u && closest < t_exit) ? 0u : rem;
     }
     tally.phase(4);
     walk_iters++;
