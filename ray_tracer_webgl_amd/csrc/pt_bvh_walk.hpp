@@ -129,21 +129,27 @@ __device__ __forceinline__ void bvh_walk(const PtKernelArgs& A, const Path& p, b
   if (!carried) cur = scan_lane ? walk_base : walk_end;
   uint32_t walk_iters = 0;
   bool stop = false; // wave-uniform: the stragglers are carried into the next wave step
+  const uint32_t half_live = ((uint32_t)n_live + 1u) >> 1;
   for (;;) {
     // Loop-carried state changes through selects only; the one real branch is the push.  A
     // lane whose walk is over rests on the spare node behind the tree (it links to itself,
     // and `through` is masked); the loop pauses for the leaf phase as soon as ANY lane's leaf
     // queue is full, so no lane ever has to stall on its own.  With fp32 nodes `cur` is
     // the node's byte offset (skip links are stored scaled): no address arithmetic.
+    // The node loop runs while somebody walks, nobody's leaf queue is full, and the walkers are not
+    // few enough to be carried — ONE scalar compare per trip: n_on >= need, with need = max(1, the carry
+    // limit from the fourth trip on) + 64 while a queue is full (conditions joined with && before a
+    // `break` are materialised as lane masks: a dozen scalar instructions per trip, pt_grid_walk.hpp).
+    const uint32_t carry_lim = A.carry_lanes < half_live ? A.carry_lanes : half_live;
+    uint32_t n_on = 0, n_full = 0;
     for (;;) {
       const bool on = cur < walk_end;
-      const unsigned long long m_on = pt_ballot(on);
-      if (m_on == 0ull) break;
-      if (pt_ballot(l_cnt == 8u) != 0ull) break;
-      {
-        const uint32_t n_on = (uint32_t)__popcll(m_on);
-        if (walk_iters >= 4u && n_on < A.carry_lanes && 2u * n_on < (uint32_t)n_live) { stop = true; break; }
-      }
+      const unsigned long long m_on = pt_ballot(cur < walk_end);
+      n_on = (uint32_t)__popcll(m_on);
+      n_full = (uint32_t)__popcll(pt_ballot(l_cnt == 8u));
+      const uint32_t lim = walk_iters >= 4u ? carry_lim : 0u;
+      const uint32_t need = (lim > 1u ? lim : 1u) + ((n_full < 1u ? n_full : 1u) << 6);
+      if (n_on < need) break;
       walk_iters++;
       tally.walk(m_on);
       float t1x, t2x, t1y, t2y, t1z, t2z;
@@ -215,6 +221,9 @@ __device__ __forceinline__ void bvh_walk(const PtKernelArgs& A, const Path& p, b
       if (pt_ballot(l_cnt != 0u) == 0ull) break;
       drain_to(4u);
     }
+    // (the node loop ended for the leaf phase: go on; it ended with walkers left and no full queue: those
+    // are the stragglers, carried; or nobody walks any more)
+    stop = n_full == 0u;
     if (stop || pt_ballot(cur < walk_end) == 0ull) break;
   }
 
