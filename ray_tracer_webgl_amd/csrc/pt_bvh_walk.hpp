@@ -196,10 +196,9 @@ __device__ __forceinline__ void bvh_walk(const PtKernelArgs& A, const Path& p, b
     // queues, those are drained and the loop resumes.  Pops are branch-free (a variable
     // shift; an empty queue is all zeros and stays so).
     for (;;) {
-      for (;;) {
+      for (unsigned long long m_busy = pt_ballot(l_cnt != 0u) & pt_ballot(q_cnt <= 4u); m_busy != 0ull;
+           m_busy = pt_ballot(l_cnt != 0u) & pt_ballot(q_cnt <= 4u)) {
         const bool busy = (l_cnt != 0u) & (q_cnt <= 4u);
-        const unsigned long long m_busy = pt_ballot(busy);
-        if (m_busy == 0ull) break;
         tally.leaf(m_busy);
         const uint32_t base = (l0 & 0xffffu) << 2;
         const uint32_t sh = busy ? 16u : 0u;
