@@ -13,7 +13,9 @@
 // whatever the entry order, and a sphere met again in a second cell meets itself).  Far-out
 // giants and spheres much larger than a cell are not gridded: every ray tests them first, through
 // scalar loads / LDS broadcasts.  The rare ray from farther away than d_near tests the grid's box
-// inflated by its own delta(D); if it enters, the lane takes the literal loop over the whole list.
+// inflated by its own delta(D); if it enters, the ray is handed over whole: to the literal loop over the
+// list, or (kernels whose entries do not fit the LDS: long lists) to the wave, 64 spheres at a time
+// (pt_kernels.hip).
 // Host-side check of the claim (registration invariant, the bound, a numpy emulation of this walk
 // against brute force): tests/test_grid.py.
 #pragma once
@@ -69,7 +71,9 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   // ... as ONE bit: sign-bit arithmetic instead of three compares.  `ds + 0` has its sign bit clear iff
   // !(ds < 0) (a -0 from underflow becomes +0); a set sign bit in c or half_b means "not provably behind"
   // (c >= +0 and half_b >= +0 is: discriminant <= half_b^2, both roots <= 0 < MIN_T).  Regular rays only
-  // (no NaN).  A -0 in c or half_b merely keeps a candidate the float compares would have dropped.
+  // (no NaN).  A -0 in c or half_b merely keeps a candidate the float compares would have dropped; c == +0
+  // with half_b >= +0 is dropped here and kept there — rightly: then disc = fl(half_b^2), sqrt(disc) = |half_b|,
+  // and the far root is exactly 0.  The padding entries (r^2 = -inf) have disc = -inf: sign bit set.
   auto pass_bit = [](float hb, float cc, float ds) -> uint32_t { return ((f2u(cc) | f2u(hb)) & ~f2u(ds + 0.0f)) >> 31; };
 
   // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is

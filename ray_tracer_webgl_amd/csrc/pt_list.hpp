@@ -14,7 +14,8 @@
 //   - discriminant < 0 (:153), or
 //   - c > 0 and half_b >= 0: the origin is outside and the sphere is behind; then
 //     disc <= fl(half_b^2), sqrtd <= |half_b|, both numerators are <= 0 and both roots
-//     are <= 0 < MIN_T.
+//     are <= 0 < MIN_T.  (The small-list and grid kernels take this test as sign-bit arithmetic, which
+//     also drops c == +0: the same three lines with `<=` for `<`.)
 // An IRREGULAR ray (NaN/Inf/zero direction, e.g. after refract() returned vec3(0)), a lane whose
 // queue overflows, or an irregular scene falls back to the literal loop: the shader's loop verbatim,
 // in ascending order, from the first sphere the queue does not cover.
