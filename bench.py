@@ -332,9 +332,9 @@ def main():
             "set_scene_ms": round((tf1 - tf0) * 1e3, 2),
             "autotune_ms": round((tf2 - tf1) * 1e3, 2),
             "cold_frame_ms": round((tf3 - tf2) * 1e3, 2),
-            "note": "context (in a fresh process ~0.2 s of this is the HIP runtime and code-object load; a second context takes 3 ms: "
+            "note": "context (in a fresh process 0.1-0.2 s of this is the HIP runtime and code-object load; a second context takes 3 ms: "
                     "tools/cold_start.py) + scene upload + structure builds + workspace; pt_tune (one cold and one measured %d-pass launch per "
-                    "usable geometry path); the first %d-spp frame with no tile-order feedback from a launch of its own shape (rank 0's share)"
+                    "geometry path whose outcome is open: none on an even grid); the first %d-spp frame with no tile-order feedback from a launch of its own shape (rank 0's share)"
                     % (tune_passes, k_frame * spp_step),
         }
         pt.reset()

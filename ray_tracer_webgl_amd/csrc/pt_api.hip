@@ -240,8 +240,15 @@ void list_paths(pt_ctx* c) {
     if (c->n_spheres <= PT_MAX_SPHERES_LDS && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_LDS;
     if (c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_SCALAR;
   }
-  if (c->have_bvh && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_BVH;
+  // The hierarchy beats the grid where a uniform grid is the wrong structure: a dense clump inside one
+  // cell of a sparse field (many entries in a cell), or many spheres too large to be gridded (every ray
+  // tests those first).  On an even field the grid won every measurement (config 2: 112 against 185 ms,
+  // config 5: 123 against 365), and a trial of the hierarchy costs the first frame of such a scene more
+  // than anything else (config 5: two 0.4-s launches): not measured there.
+  const bool grid_even = c->have_grid && c->grid.max_cell_entries <= 16u && c->grid.n_always <= 8u;
+  if (c->have_bvh && !grid_even && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_BVH;
   if (c->have_grid && c->n_trials < 4) c->trial_paths[c->n_trials++] = PT_GEOM_GRID;
+  if (c->n_trials == 1) c->geom_tuned = c->trial_paths[0];  // nothing to measure
 }
 
 #define PT_KFN(name) reinterpret_cast<const void*>(name)
