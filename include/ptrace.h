@@ -63,7 +63,9 @@ enum {
  *          scene without a grid falls back to BVH, then SCALAR
  *   AUTO   (default) after pt_set_spheres the first launch runs cold (unmeasured), the next
  *          ones measure one usable path each, and the fastest (time per camera sample) is
- *          used from then on                                                                 */
+ *          used from then on.  Paths whose outcome is not open are not measured: the list
+ *          walks beside a structure on more than 64 spheres, the hierarchy beside an even
+ *          grid (no cell with more than 16 entries, at most 8 always-tested spheres)       */
 enum {
   PT_GEOM_AUTO = 0,
   PT_GEOM_LDS = 1,
