@@ -176,7 +176,9 @@ def exact_root(o, d, c, r2):
     cc = fma(oc[2], oc[2], fma(oc[1], oc[1], fma(oc[0], oc[0], -r2)))
     a = fma(d[:, 2], d[:, 2], fma(d[:, 1], d[:, 1], f32(d[:, 0] * d[:, 0])))
     disc = fma(-a, cc, f32(hb * hb))
-    ok = ~(disc < 0) & ~((cc > 0) & (hb >= 0))
+    # the kernels' candidate test, as they take it: one bit of sign arithmetic (pt_grid_walk.hpp pass_bit)
+    bits = lambda x: np.asarray(x, np.float32).view(np.uint32)
+    ok = (((bits(cc) | bits(hb)) & ~bits(f32(disc + np.float32(0.0)))) >> np.uint32(31)).astype(bool)
     with np.errstate(invalid="ignore", divide="ignore"):
         sq = np.sqrt(np.where(ok, disc, 0).astype(np.float32))
         v = f32(f32(-hb - sq) / a)
