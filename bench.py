@@ -192,7 +192,9 @@ def main():
                          "default = the reference's own 1-spp frame loop on State::default")
     ap.add_argument("--steps", type=int, default=None, help="default: the config's converged frame (16 / 64)")
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--steps-per-launch", type=int, default=16)
+    ap.add_argument("--steps-per-launch", type=int, default=None,
+                    help="default: 16, and 16 x N for a rank of N in strong scaling (a rank's rows are 1/N of the frame: "
+                         "the same slab memory as the single-GPU launch, and a longer launch loses less to its start and drain)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp-per-pass", type=int, default=16)
@@ -282,12 +284,15 @@ def main():
     p.band_rows, p.band_index, p.band_count = ptdist.band_of(rank, world, band_rows)
     p.time_step = abi.PT_TIME_STEP_DECORRELATED  # independent passes (include/ptrace.h)
 
-    spl = max(1, min(args.steps_per_launch, max(steps, 1)))
+    spl_frame = 16  # steps per launch of the single-GPU workload
+    spl_want = args.steps_per_launch or (spl_frame * world if (world > 1 and not weak) else spl_frame)
+    spl = max(1, min(spl_want, max(steps, 1)))
     ppl = spl * pps  # passes per launch
-    # the weak-scaling point after a strong main region needs world x the passes per launch
-    # (over 1/world of the rows: the same slab memory as the single-GPU launch)
+    # the weak-scaling point after a strong main region renders world x the passes per step, spl_frame steps per
+    # launch (over 1/world of the rows: the same slab memory as the single-GPU launch)
     want_weak_series = world > 1 and not weak and not args.no_weak_series
-    reserve = ppl * (world if want_weak_series else 1)
+    spl_weak = max(1, min(args.steps_per_launch or spl_frame, max(steps, 1)))
+    reserve = max(ppl, spl_weak * pps_frame * world) if want_weak_series else ppl
 
     def sync_all():
         torch.cuda.synchronize()
@@ -387,15 +392,15 @@ def main():
     weak_series = None
     if want_weak_series:
         pps_w = pps_frame * world
-        k_w = min(steps, spl)
+        k_w = min(steps, spl_weak)
         pt.reset()
-        run_steps(k_w, 1000.0, pps_w, spl)  # settle the tile order for this launch shape
+        run_steps(k_w, 1000.0, pps_w, spl_weak)  # settle the tile order for this launch shape
         gather(pt.accum_tensor)
         sync_all()
         pt.reset()
         sync_all()
         f0 = time.perf_counter()
-        run_steps(k_w, 0.0, pps_w, spl)
+        run_steps(k_w, 0.0, pps_w, spl_weak)
         gather(pt.accum_tensor)
         sync_all()
         f1 = time.perf_counter()
