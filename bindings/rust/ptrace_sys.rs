@@ -74,7 +74,8 @@ pub const PT_OPT_RUSSIAN_ROULETTE: c_int = 5;   // opt-in, 0 = off: the referenc
 //     pt_set_params(ctx, &p);
 //     pt_render_frame(ctx, state.even_odd_count);           // webgl::render: trace + blend into the ping-pong textures
 //     if should_save { pt_read_canvas(ctx, pixels.as_mut_ptr()); }
-// A run of ticks with nothing else happening (no input) is one call:
+// A run of ticks with nothing else happening (no input: no key held; should_average on — without it only the
+// first tick draws, src/state.rs:443-447) is one call:
 //     p.time_step = frame_interval_ms; pt_set_params(ctx, &p);
 //     pt_render_frames(ctx, state.even_odd_count, state.max_render_count, n);   // one hipGraph replayed n times
 //     for _ in 1..n { state::update_render_globals(&mut state); }

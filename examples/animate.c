@@ -4,7 +4,9 @@
  * RGBA8 ping-pong textures by the shader's render() rule (static/shader.frag:387-404, src/webgl.rs:180-205).
  * The ticks are ONE pt_render_frames call: the uniforms of the first tick go up once, libptrace replays one
  * captured hipGraph n times with u_time / render_count / the texture roles counted on the device.  The
- * host's State follows with update_render_globals, as it would after n rAF callbacks.
+ * host's State follows with update_render_globals, as it would after n rAF callbacks.  (Valid because nothing
+ * but the clock changes between these ticks: should_average is on and no movement key is held; otherwise the
+ * ticks are issued one by one with pt_render_frame, as ray_tracer_webgl_amd/app.py FrameLoop.frames does.)
  *
  *   make -C examples && examples/animate out.ppm 640 351 320
  */

@@ -294,7 +294,13 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
  * state of State::update_render_globals (src/state.rs:443-450) kept on the device: frame k of the
  * call renders at u_time = time + float(first_pass + k) * time_step with
  * render_count = min(params.render_count + k, max_render_count) and even_odd_count + k — the bits
- * of n_frames pt_render_frame calls made with those uniforms.  The accumulation buffer of
+ * of n_frames pt_render_frame calls made with those uniforms.  That equals n_frames ticks of the
+ * reference's loop only while nothing but the clock changes between them: with should_average off
+ * just the first tick draws (update_render_globals clears should_render, src/state.rs:443-447), with a
+ * movement key held every tick has its own camera — issue such ticks one by one (pt_render_frame).
+ * The graph is re-captured only when something it bakes in has changed (uniforms, scene size, launch
+ * shape, stream).  NOT on a context bound to the legacy default stream (PT_STREAM_LEGACY): HIP does not
+ * capture that stream, the call returns PT_ERR_INVALID there.  The accumulation buffer of
  * pt_render / pt_resolve is not involved.  pt_read_canvas / pt_read_texture copy RGBA8 texels out
  * (host or device pointer; they synchronise), pt_write_texture copies a texture in. */
 int pt_clear_textures(pt_ctx* ctx);

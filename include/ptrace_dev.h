@@ -20,6 +20,18 @@ long pt_debug_counters(pt_ctx* ctx, unsigned long long* out, size_t cap);
 /* Per wave {start, queue dry (0 = never saw it dry), end} of the last counted launch, in 100 MHz
  * ticks.  Returns the number of waves written (at most cap_waves), < 0 when there is no log. */
 long pt_debug_wave_log(pt_ctx* ctx, unsigned long long* out, size_t cap_waves);
+/* Watchdog for the A/B tools (tools/ab_kernels.py, tools/sweep_knobs.py, ...): waits for everything
+ * enqueued on the context's stream WITHOUT blocking in the driver — an event is recorded and polled
+ * (hipEventQuery, 1 ms apart) until it has fired or timeout_ms have passed.  Returns 0 when the stream
+ * is idle, 1 on timeout (the caller reports and exits non-zero: an experimental kernel that never
+ * finishes must not hold a GPU box until gpurun's own limit, round 3), < 0 on a HIP error. */
+int pt_debug_wait(pt_ctx* ctx, unsigned timeout_ms);
+/* pt_build_grid (ptrace.h) in the layout the grid kernels use when a scene's entries do not fit the LDS and
+ * are gathered from global memory: the cells' runs of entries in Morton order of their cells
+ * (csrc/pt_grid.hpp morton_runs).  Same arguments, counts and return codes.  For tests/test_grid.py. */
+int pt_build_grid_runs(const PtSphere* spheres, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
+                       float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
+                       uint32_t* entry_index, size_t n_index);
 
 #ifdef __cplusplus
 }

@@ -25,3 +25,23 @@ for grp in \
 done
 python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the other BASELINE configs through the same bench line, each with its own kernel trace and PMC passes: the records
+# bench.py attaches to `--config 3 / 4 / 5` lines (profiles/summarize.py --merge <dirs> writes profiles/pmc_traffic.json)
+for CFG in ${PT_COLLECT_CONFIGS:-3 4 5}; do
+  OC=gpurun_out/prof_${TAG}_c$CFG
+  mkdir -p $OC
+  BC="python3 bench.py --config $CFG --no-cpu-baseline --no-work-count --no-list-walk --no-first-frame"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OC/kt -- $BC > $OC/kt.log 2>&1
+  i=0
+  for grp in \
+    "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
+    "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32" \
+    "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" \
+    "GRBM_GUI_ACTIVE FETCH_SIZE" \
+    "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ; do
+    i=$((i+1))
+    rocprofv3 --pmc $grp --output-format csv -d $OC/pmc$i -- $BC > $OC/pmc$i.log 2>&1
+  done
+  python3 profiles/summarize.py $OC > $OC/summary.txt 2>&1
+  tail -40 $OC/summary.txt
+done

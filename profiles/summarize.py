@@ -10,8 +10,34 @@ import os
 import sys
 from collections import defaultdict
 
+if sys.argv[1] == "--merge":
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+    doc = json.load(open(dst)) if os.path.exists(dst) else {}
+    recs = doc.get("records") or ([doc] if doc.get("kernel") else [])
+    for src in sys.argv[2:]:
+        rec = json.load(open(os.path.join(src, "pmc_traffic.json")))
+        recs = [r for r in recs if not (r.get("kernel") == rec.get("kernel") and str(r.get("config", "2")) == str(rec.get("config", "2")))]
+        recs.append(rec)
+        print("merged %s config %s from %s" % (rec.get("kernel"), rec.get("config"), src))
+    recs.sort(key=lambda r: str(r.get("config", "2")))
+    json.dump({"note": "one record per (kernel, config): the counter-derived figures bench.py attaches (labelled PRIOR) to a line of the "
+                       "same kernel, config and launch shape; written by profiles/summarize.py from a profiles/collect.sh run",
+               "records": recs}, open(dst, "w"), indent=1)
+    sys.exit(0)
 d = sys.argv[1]
 out = {}
+# the bench line of the profiled command (kt.log holds its stdout): which config, which launch shape
+bench = {}
+try:
+    for line in open(os.path.join(d, "kt.log")):
+        if line.startswith("{") and '"metric"' in line:
+            bench = json.loads(line)
+except Exception:
+    bench = {}
+cfg_name = (bench.get("config", {}).get("workload", "config2").split(":")[0] or "config2")
+cfg_key = cfg_name.replace("config", "")
+ppl = int(bench.get("config", {}).get("passes_per_launch", 64))
+spp_pass = int(bench.get("config", {}).get("spp_per_pass", 16))
 for f in glob.glob(os.path.join(d, "kt", "**", "*_kernel_stats.csv"), recursive=True):
     print("== kernel-trace stats (%s)" % os.path.relpath(f, d))
     for row in csv.DictReader(open(f)):
@@ -100,8 +126,10 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
     out["pt_trace_kernel_hbm_bytes_per_launch"] = int(traffic)
     print("  HBM traffic per launch (WRITE_SIZE + 2*FETCH_SIZE): %.4g bytes" % traffic)
     rec = {"pt_trace_kernel_hbm_bytes_per_launch": int(traffic), "kernel": out.get("pmc_kernel"),
-           "workload": "bench.py --steps 16 --warmup 16 (config 2, 64 passes of 16 spp per launch; pt_tune runs each usable path, then the timed launches use the fastest)",
-           "spp_per_pass": 16, "passes_per_launch": 64, "hbm_bytes_per_pass": int(traffic / 64),
+           "config": cfg_key,
+           "workload": "bench.py --config %s (%s; %d passes of %d spp per launch; pt_tune runs each usable path, then the timed launches use the fastest)"
+                       % (cfg_key, bench.get("config", {}).get("workload", "?"), ppl, spp_pass),
+           "spp_per_pass": spp_pass, "passes_per_launch": ppl, "hbm_bytes_per_pass": int(traffic / ppl),
            "profile": "profiles/" + os.path.basename(os.path.normpath(d)).replace("prof_", "") + "_summary.txt",
            "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]}
     # what the kernel actually issued (the hierarchy walk skips most of the algorithmic tests):
@@ -114,7 +142,8 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
         rec["kernel_cycles"] = cycles
         rec["valu_issue_frac"] = 2.0 * pm["SQ_INSTS_VALU"] / (1024.0 * cycles)
         for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_LDS_BANK_CONFLICT",
-                  "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"):
+                  "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES",
+                  "SQ_INSTS_VMEM_RD", "TCC_HIT_sum", "TCC_MISS_sum"):
             if k in pm:
                 rec[k.lower()] = pm[k]
     # the same kernel's average duration in the kernel-trace pass of the same command
@@ -123,3 +152,5 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
         rec["kernel_ms"] = ks["avg_ms"]
     json.dump(rec, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
+
+# merge the per-config records into the committed file bench.py reads:  summarize.py --merge <dir> [<dir> ...]

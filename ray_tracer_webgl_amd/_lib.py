@@ -86,11 +86,38 @@ SIGNATURES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  libptrace.so needs libamdhip64.so.7; PyTorch ships its own copy of that
+    library.  Whichever is loaded first serves both (same SONAME) — as long as it is PyTorch's: with the system
+    copy loaded first, a later `import torch` brings its own runtime as a second one, and the second runtime to
+    touch the GPU finds none ("No HIP GPUs are available" from PathTracer(use_torch=True), dist.py or bench.py,
+    depending on import order).  So if PyTorch is installed but not imported yet, its copy is loaded here, before
+    libptrace.so, exactly as if `import torch` had come first.  Without PyTorch the system runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # (an unusable copy: the system runtime serves libptrace.so, and use_torch will say what is wrong)
+
+
 def load():
     """Return the ctypes handle of libptrace.so with every signature declared."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     path = os.environ.get("PT_LIB", LIB_PATH)  # dev: A/B another build of the same ABI
     if not os.path.exists(path):
         raise ImportError(

@@ -74,14 +74,21 @@ class FrameLoop:
         return True
 
     def frames(self, n, first_now_ms, interval_ms):
-        """n rAF ticks at a constant frame interval with nothing else happening in between (no input:
-        update_position changes nothing, should_render stays true while unpaused) — one
-        pt_render_frames call: the first tick's uniforms go up once, the graph of one frame is
-        replayed n times, u_time / render_count / even-odd advance on the device exactly as
-        n calls of frame(first_now_ms + k * interval_ms) would advance them.  Reference mode only."""
+        """n rAF ticks at a constant frame interval, i.e. exactly what n calls of
+        frame(first_now_ms + k * interval_ms) do; returns how many of them drew a frame.  When nothing but
+        the clock changes between the ticks (averaging on, no movement key held: update_position changes
+        nothing, should_render stays true while unpaused) they are ONE pt_render_frames call: the first
+        tick's uniforms go up once, the graph of one frame is replayed n times, u_time / render_count /
+        even-odd advance on the device as the n calls would advance them.  Otherwise the ticks differ in
+        more than the clock — with should_average off only the first one draws (update_render_globals
+        clears should_render, src/state.rs:443-447), with a key held every tick moves the camera
+        (update_position, src/state.rs:411-441) — and they are issued one by one.  Reference mode only."""
         assert self.mode == "reference" and n >= 1
         st = self.state
-        assert not st.view().is_paused, "a paused State renders one frame per camera change, not a series"
+        v0 = st.view()
+        assert not v0.is_paused, "a paused State renders one frame per camera change, not a series"
+        if not v0.should_average or st.keys != 0:
+            return sum(1 for k in range(n) if self.frame(first_now_ms + k * interval_ms))
         st.update_position(first_now_ms - self.prev_now)
         if not st.should_render(False):
             return 0

@@ -7,6 +7,8 @@
 // (graph-capturable once pt_reserve_passes has sized the workspace); no CPU fallback exists.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -14,17 +16,21 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ptrace.h"
 #include "../../include/ptrace_dev.h"
 #include "pt_bvh.hpp"
 #include "pt_grid.hpp"
+#include "pt_extra.h"
 #include "pt_kernel_args.h"
 
 #define PT_API extern "C" __attribute__((visibility("default")))
 
-// single translation unit: the kernels are compiled into this object (no -fgpu-rdc needed)
+// the kernels every context uses are compiled into this object (no -fgpu-rdc needed); the opt-in builds
+// (Russian roulette, measuring twins) are the translation unit pt_kernels_extra.hip — a code object of their
+// own, which the HIP runtime loads when one of them is first asked for (extra_kernel below)
 #include "pt_kernels.hip"
 
 static thread_local std::string g_create_error;
@@ -104,8 +110,7 @@ struct pt_ctx {
   uint32_t* d_frame_ctr = nullptr;
   hipGraphExec_t frame_exec = nullptr;   // one frame (trace + blend + advance), captured once per uniform set
   uint64_t epoch = 0;                    // bumped by everything a captured frame bakes in
-  uint64_t frame_exec_epoch = ~0ull;
-  uint32_t frame_exec_even_odd = 0, frame_exec_max_rc = 0;
+  unsigned char frame_plan[1024] = {0};  // the FramePlan the cached graph was captured from (compared bytewise)
   // counters + timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool
@@ -174,6 +179,13 @@ int ensure_buffers(pt_ctx* c) {
     PT_HIP(c, hipMalloc(&c->d_tile_cost, tiles * sizeof(uint32_t)));
     PT_HIP(c, hipMalloc(&c->d_tile_order, tiles * sizeof(uint32_t)));
     PT_HIP(c, hipMemsetAsync(c->d_tile_cost, 0, tiles * sizeof(uint32_t), c->stream));
+    {
+      // the identity order from the start: a launch that skips the order kernel (because an earlier one was only
+      // CAPTURED into a caller's hipGraph and has not run yet) must still find every tile exactly once
+      std::vector<uint32_t> ident(tiles);
+      for (size_t i = 0; i < tiles; i++) ident[i] = (uint32_t)i;
+      PT_HIP(c, hipMemcpy(c->d_tile_order, ident.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     c->tile_cap = tiles;
     c->tile_order_valid = false;
   }
@@ -251,9 +263,24 @@ void list_paths(pt_ctx* c) {
   if (c->n_trials == 1) c->geom_tuned = c->trial_paths[0];  // nothing to measure
 }
 
+// LDS a walk kernel may fill with its staged scene: what is left beside a 1024-thread workgroup's parked path state
+constexpr size_t kWalkLdsMax = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
+constexpr size_t walk_lds_room() { return kWalkLdsMax - (size_t)PT_PARK_STRIDE * 4 * 1024; }
+
 #define PT_KFN(name) reinterpret_cast<const void*>(name)
+
+// a kernel of pt_kernels_extra.hip; its first use loads that code object and lifts its dynamic-LDS limit
+const void* extra_kernel(int id) {
+  static std::atomic<bool> ready[PT_X_COUNT];
+  const void* k = pt_extra_kernel(id);
+  if (k && !ready[id].exchange(true)) {
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsMax);
+    (void)hipGetLastError();  // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
+  }
+  return k;
+}
 // the Russian-roulette build of a kernel when the option is on
-#define PT_PICK(rr, name) ((rr) ? PT_KFN(name##_rr) : PT_KFN(name))
+#define PT_PICK(rr, name, id) ((rr) ? extra_kernel(id) : PT_KFN(name))
 
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
   uint32_t g = (n + block - 1) / block;
@@ -321,11 +348,7 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_bvh_gmem),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
-  for (const void* k : {reinterpret_cast<const void*>(pt_trace_kernel_grid), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells),
-                        reinterpret_cast<const void*>(pt_trace_kernel_grid_gmem), reinterpret_cast<const void*>(pt_trace_kernel_bvh_count),
-                        reinterpret_cast<const void*>(pt_trace_kernel_grid_count), reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count),
-                        PT_KFN(pt_trace_kernel_scalar_rr), PT_KFN(pt_trace_kernel_bvh_rr), PT_KFN(pt_trace_kernel_bvh_nodes_rr),
-                        PT_KFN(pt_trace_kernel_grid_rr), PT_KFN(pt_trace_kernel_grid_cells_rr)})
+  for (const void* k : {PT_KFN(pt_trace_kernel_grid), PT_KFN(pt_trace_kernel_grid_cells), PT_KFN(pt_trace_kernel_grid_gmem)})
     (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipGetLastError(); // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
   int rc = ensure_buffers(c);
@@ -428,6 +451,14 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   // ... and the uniform grid of PT_GEOM_GRID (same precondition)
   ptgrid::Grid grid;
   const bool have_grid = regular && ptgrid::build(geom.data(), radii.data(), n, &grid);
+  // entries that will not be staged in the LDS (bind_grid) are gathered from L2: their runs in Morton order of the cells
+  if (have_grid && PT_GRID_LDS_CELLS(grid.cells.size()) + (size_t)grid.n_entries * 16 > walk_lds_room()) {
+    int mode = 2;
+#ifdef PT_DEV_KNOBS  // A/B only: PT_PAD_RUNS = 0 plain layout, 1 padded runs in Morton order, 2 Morton order (default), 3 padded runs
+    if (getenv("PT_PAD_RUNS")) mode = atoi(getenv("PT_PAD_RUNS"));
+#endif
+    if (mode) (void)ptgrid::morton_runs(&grid, mode != 2, mode != 3);
+  }
   {
     // the stream may still be reading the previous scene
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -551,8 +582,12 @@ PT_API int pt_set_params(pt_ctx* c, const PtParams* p) {
       c->local_rows = old_rows;
       return rc;
     }
-    // a different set of rows: the accumulated image no longer applies
+    // a different set of rows: the accumulated image no longer applies, and neither do the frame textures
     PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
+    {
+      int rc2 = pt_clear_textures(c);
+      if (rc2 != PT_OK) return rc2;
+    }
     c->total_spp = 0;
     c->captured = false;  // whatever a replayed graph accumulated is gone with the old partition
   }
@@ -574,6 +609,10 @@ PT_API int pt_resize(pt_ctx* c, uint32_t width, uint32_t height) {
   c->local_rows = height;
   if (c->accum_bound) { c->accum_bound = false; c->accum = nullptr; }
   int rc = ensure_buffers(c);
+  if (rc != PT_OK) return rc;
+  // update_render_dimensions_to_match_window re-specifies both textures as empty on EVERY resize
+  // (src/state.rs:382-396), growing or not: alpha 0 = "no data" (static/shader.frag:391)
+  rc = pt_clear_textures(c);
   if (rc != PT_OK) return rc;
   return pt_reset_accum(c);
 }
@@ -801,14 +840,14 @@ static size_t bind_hierarchy(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& 
   const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
   const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
   if (need_all <= lds_room) {
-    *kfn = c->count_work ? PT_KFN(pt_trace_kernel_bvh_count) : PT_PICK(rr, pt_trace_kernel_bvh);
+    *kfn = c->count_work ? extra_kernel(PT_X_BVH_COUNT) : PT_PICK(rr, pt_trace_kernel_bvh, PT_X_BVH_RR);
     return need_all;
   }
   if (need_nodes <= lds_room) {
-    *kfn = PT_PICK(rr, pt_trace_kernel_bvh_nodes);
+    *kfn = PT_PICK(rr, pt_trace_kernel_bvh_nodes, PT_X_BVH_NODES_RR);
     return need_nodes;
   }
-  *kfn = PT_PICK(rr, pt_trace_kernel_bvh_gmem);
+  *kfn = PT_PICK(rr, pt_trace_kernel_bvh_gmem, PT_X_BVH_GMEM_RR);
   return 0;
 }
 
@@ -835,14 +874,14 @@ static size_t bind_grid(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& A, co
   const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
   const size_t need_all = need_cells + (size_t)g.n_entries * 16;
   if (need_all <= lds_room) {
-    *kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_count) : PT_PICK(rr, pt_trace_kernel_grid);
+    *kfn = c->count_work ? extra_kernel(PT_X_GRID_COUNT) : PT_PICK(rr, pt_trace_kernel_grid, PT_X_GRID_RR);
     return need_all;
   }
   if (need_cells <= lds_room) {
-    *kfn = c->count_work ? PT_KFN(pt_trace_kernel_grid_cells_count) : PT_PICK(rr, pt_trace_kernel_grid_cells);
+    *kfn = c->count_work ? extra_kernel(PT_X_GRID_CELLS_COUNT) : PT_PICK(rr, pt_trace_kernel_grid_cells, PT_X_GRID_CELLS_RR);
     return need_cells;
   }
-  *kfn = PT_PICK(rr, pt_trace_kernel_grid_gmem);
+  *kfn = PT_PICK(rr, pt_trace_kernel_grid_gmem, PT_X_GRID_GMEM_RR);
   return 0;
 }
 
@@ -890,8 +929,8 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   const void* kfn = nullptr;
   uint32_t block = 256;
   if (path == PT_GEOM_BVH || path == PT_GEOM_GRID) {
-    const size_t lds_max = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
-    const size_t lds_room = lds_max - (size_t)PT_PARK_STRIDE * 4 * 1024;  // beside a 1024-thread workgroup's parking
+    const size_t lds_max = kWalkLdsMax;
+    const size_t lds_room = walk_lds_room();
     const size_t scene = path == PT_GEOM_BVH ? bind_hierarchy(c, rr, lds_room, A, &kfn) : bind_grid(c, rr, lds_room, A, &kfn);
     A.lds_scene_bytes = (uint32_t)scene;
     // tail mode costs ~n/64 rounds per live ray, the walk a roughly constant ~1500 issue slots
@@ -906,9 +945,10 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     // SCAN reads (their per-lane gathers — shading, tail mode — still come from the copy)
     const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
     lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
-    kfn = path == PT_GEOM_SMALL ? PT_PICK(rr, pt_trace_kernel_small)
+    kfn = path == PT_GEOM_SMALL ? (c->count_work ? extra_kernel(PT_X_SMALL_COUNT) : PT_PICK(rr, pt_trace_kernel_small, PT_X_SMALL_RR))
           : path == PT_GEOM_LDS ? PT_KFN(pt_trace_kernel)
-                                : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar) : PT_PICK(rr, pt_trace_kernel_scalar_nolds));
+                                : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar, PT_X_SCALAR_RR)
+                                            : PT_PICK(rr, pt_trace_kernel_scalar_nolds, PT_X_SCALAR_NOLDS_RR));
     // 256-thread workgroups while several fit per CU; one 1024-thread workgroup per CU when the list
     // takes most of the 160 KiB LDS
     block = lds > 40 * 1024 ? 1024u : 256u;
@@ -983,7 +1023,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   if (capturing && c->count_work)
     return fail(c, PT_ERR_INVALID, "pt_render_passes: PT_OPT_COUNT_WORK (measuring twin: allocates its wave log) cannot be captured into a hipGraph");
   A.wave_log = nullptr;
-  if (c->count_work && (path == PT_GEOM_BVH || path == PT_GEOM_GRID)) { // measuring twin: not a product launch, may allocate
+  if (c->count_work && (path == PT_GEOM_BVH || path == PT_GEOM_GRID || path == PT_GEOM_SMALL)) { // measuring twin: not a product launch, may allocate
     const size_t n_waves = (size_t)grid * (block / 64);
     if (n_waves * 3 > c->wave_log_cap) {
       if (c->d_wave_log) PT_HIP(c, hipFree(c->d_wave_log));
@@ -1018,7 +1058,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost,
                        c->d_tile_order, A.tiles_x * A.tiles_y);
     PT_HIP(c, hipGetLastError());
-    c->tile_order_valid = true;
+    if (!capturing) c->tile_order_valid = true;  // (a captured order kernel has not run: the next direct launch runs its own)
   }
   if (capturing) trial = -1;
   if (trial >= 0) {
@@ -1065,34 +1105,62 @@ PT_API int pt_render(pt_ctx* c) { return pt_render_passes(c, 1); }
 // other texture.  Nothing crosses PCIe: the textures of src/webgl.rs:82-123 live in HBM.
 namespace {
 
-// enqueue one frame; ctr = the device cell holding this frame's number in its series
-int enqueue_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_render_count, bool advance) {
+// Everything a frame bakes into its launches: decided BEFORE anything is enqueued (prepare_launch queries
+// occupancy and the autotuner's events — not things to do inside a stream capture), and what the cached graph of
+// pt_render_frames is keyed on.
+struct FramePlan {
   Launch L;
-  int rc = prepare_launch(c, 1, false, &L);
+  const uint32_t* ctr = nullptr;  // the device cell holding a frame's number in its series
+  uint32_t even_odd0 = 0;
+  int max_render_count = 0, render_count0 = 0, should_average = 0;
+  float last_frame_weight = 0.f;
+  hipStream_t stream = nullptr;
+  float4* slab = nullptr;
+  uint32_t* tex0 = nullptr; uint32_t* tex1 = nullptr; uint32_t* canvas = nullptr;
+};
+static_assert(sizeof(FramePlan) <= sizeof(pt_ctx::frame_plan), "pt_ctx::frame_plan must hold a FramePlan");
+
+int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_render_count, FramePlan* F) {
+  memset(static_cast<void*>(F), 0, sizeof *F);  // (padding too: plans are compared bytewise)
+  int rc = prepare_launch(c, 1, false, &F->L);
   if (rc != PT_OK) return rc;
-  L.A.frame_ctr = ctr;
-  L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
-  L.A.wave_log = nullptr;
-  if (!c->tile_order_valid) {
-    hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost, c->d_tile_order,
-                       L.A.tiles_x * L.A.tiles_y);
-    PT_HIP(c, hipGetLastError());
-    c->tile_order_valid = true;
-  }
+  F->L.A.frame_ctr = ctr;
+  F->L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
+  F->L.A.wave_log = nullptr;
+  F->ctr = ctr; F->even_odd0 = even_odd0; F->max_render_count = max_render_count;
+  F->render_count0 = c->params.render_count; F->should_average = c->params.should_average;
+  F->last_frame_weight = c->params.last_frame_weight;
+  F->stream = c->stream; F->slab = c->d_slab;
+  F->tex0 = c->d_tex[0]; F->tex1 = c->d_tex[1]; F->canvas = c->d_canvas;
+  return PT_OK;
+}
+
+// enqueue one planned frame (capture-safe: launches only)
+int enqueue_frame(pt_ctx* c, FramePlan& F, bool advance) {
   {
-    void* kargs[] = {&L.A};
-    PT_HIP(c, hipLaunchKernel(L.kfn, dim3(L.grid), dim3(L.block), kargs, L.lds, c->stream));
+    void* kargs[] = {&F.L.A};
+    PT_HIP(c, hipLaunchKernel(F.L.kfn, dim3(F.L.grid), dim3(F.L.block), kargs, F.L.lds, c->stream));
   }
   // the frame's one pass sits in the slab ({sum r, g, b, spp} per pixel): blend straight from there
   const uint32_t n_pix = c->local_rows * c->width;
   hipLaunchKernelGGL(pt_frame_blend_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream, c->d_slab, c->d_tex[0],
-                     c->d_tex[1], c->d_canvas, n_pix, ctr, c->params.render_count, even_odd0, max_render_count,
-                     c->params.should_average, c->params.last_frame_weight);
+                     c->d_tex[1], c->d_canvas, n_pix, F.ctr, F.render_count0, F.even_odd0, F.max_render_count,
+                     F.should_average, F.last_frame_weight);
   PT_HIP(c, hipGetLastError());
   if (advance) {
     hipLaunchKernelGGL(pt_frame_advance_kernel, dim3(1), dim3(64), 0, c->stream, c->d_frame_ctr, &c->d_counters[PT_CTR_HEAD]);
     PT_HIP(c, hipGetLastError());
   }
+  return PT_OK;
+}
+
+// the tile order a frame finds must exist (frames report no costs and never run the order kernel themselves)
+int ensure_tile_order(pt_ctx* c) {
+  if (c->tile_order_valid) return PT_OK;
+  hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost, c->d_tile_order,
+                     ((c->width + 7) / 8) * ((c->local_rows + 7) / 8));
+  PT_HIP(c, hipGetLastError());
+  c->tile_order_valid = true;
   return PT_OK;
 }
 
@@ -1121,8 +1189,13 @@ PT_API int pt_render_frame(pt_ctx* c, uint32_t even_odd_count) {
   if (rc != PT_OK) return rc;
   if (c->local_rows == 0) return PT_OK;
   PT_HIP(c, hipSetDevice(c->device));
+  FramePlan F;
+  rc = plan_frame(c, c->d_frame_ctr + 1, even_odd_count, 0x7fffffff, &F);  // frame 0 of a series of one
+  if (rc != PT_OK) return rc;
+  rc = ensure_tile_order(c);
+  if (rc != PT_OK) return rc;
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
-  rc = enqueue_frame(c, c->d_frame_ctr + 1, even_odd_count, 0x7fffffff, false);  // frame 0 of a series of one
+  rc = enqueue_frame(c, F, false);
   if (rc != PT_OK) return rc;
   c->launches++;
   c->samples += (uint64_t)c->local_rows * c->width * (uint64_t)c->params.samples_per_pixel;
@@ -1139,28 +1212,31 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
   (void)hipStreamIsCapturing(c->stream, &cap);
   if (cap != hipStreamCaptureStatusNone)
     return fail(c, PT_ERR_INVALID, "pt_render_frames: the stream is being captured already (this call replays its own graph)");
-  // (re)capture ONE frame when the uniforms, the scene or anything else a launch bakes in has changed
-  if (!c->frame_exec || c->frame_exec_epoch != c->epoch || c->frame_exec_even_odd != even_odd_count ||
-      c->frame_exec_max_rc != max_render_count) {
+  // hipStreamBeginCapture is refused on the legacy default stream (PT_STREAM_LEGACY, what a context bound to
+  // torch's default stream runs on): say so instead of failing inside the capture
+  if (c->stream == hipStreamLegacy || c->stream == nullptr)
+    return fail(c, PT_ERR_INVALID, "pt_render_frames: the context runs on the legacy default stream (PT_STREAM_LEGACY), which cannot be "
+                                   "captured into a hipGraph; give it a stream of its own (pt_set_stream(ctx, NULL) or a created stream) "
+                                   "or issue the ticks with pt_render_frame");
+  // everything a frame bakes in, decided outside the capture; the cached graph is reused while that is unchanged
+  // (pt_set_params with the same values, as a frame loop issues before every series, does not re-capture)
+  FramePlan F;
+  rc = plan_frame(c, c->d_frame_ctr, even_odd_count, (int)max_render_count, &F);
+  if (rc != PT_OK) return rc;
+  rc = ensure_tile_order(c);  // outside the capture: it runs once, not per frame
+  if (rc != PT_OK) return rc;
+  if (!c->frame_exec || memcmp(&F, &c->frame_plan, sizeof F) != 0) {
     if (c->frame_exec) { (void)hipGraphExecDestroy(c->frame_exec); c->frame_exec = nullptr; }
-    if (!c->tile_order_valid) {  // outside the capture: it runs once, not per frame
-      hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost, c->d_tile_order,
-                         ((c->width + 7) / 8) * ((c->local_rows + 7) / 8));
-      PT_HIP(c, hipGetLastError());
-      c->tile_order_valid = true;
-    }
     hipGraph_t graph = nullptr;
     PT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    rc = enqueue_frame(c, c->d_frame_ctr, even_odd_count, (int)max_render_count, true);
+    rc = enqueue_frame(c, F, true);
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc != PT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(c, PT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
     e = hipGraphInstantiate(&c->frame_exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) { c->frame_exec = nullptr; return fail(c, PT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-    c->frame_exec_epoch = c->epoch;
-    c->frame_exec_even_odd = even_odd_count;
-    c->frame_exec_max_rc = max_render_count;
+    memcpy(static_cast<void*>(&c->frame_plan), &F, sizeof F);
   }
   // the series starts at frame 0 with an empty queue; every replay leaves both ready for the next
   PT_HIP(c, hipMemsetAsync(c->d_frame_ctr, 0, sizeof(uint32_t), c->stream));
@@ -1227,6 +1303,26 @@ PT_API long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_wav
   const size_t n = c->wave_log_n < cap_waves ? c->wave_log_n : cap_waves;
   if (hipMemcpy(out, c->d_wave_log, n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
   return (long)n;
+}
+
+PT_API int pt_debug_wait(pt_ctx* c, unsigned timeout_ms) {
+  if (!c) return -1;
+  if (hipSetDevice(c->device) != hipSuccess) return -2;
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -2;
+  int rc = -2;
+  if (hipEventRecord(ev, c->stream) == hipSuccess) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipSuccess) { rc = 0; break; }
+      if (e != hipErrorNotReady) { (void)hipGetLastError(); rc = -2; break; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) { rc = 1; break; }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+  }
+  if (rc != 1) (void)hipEventDestroy(ev);  // (a pending event is left alone: destroying it could block like a synchronise)
+  return rc;
 }
 
 PT_API int pt_synchronize(pt_ctx* c) {

@@ -53,6 +53,15 @@
 //             fit), then the always-tested spheres, padded to four with entries that can never
 //             pass (r*r = -inf)
 //   entry_index : original sphere index per entry (0xffffffff = padding)
+//
+// morton_runs() re-lays the entries out for the kernels that GATHER them from global memory / L2 (scenes whose
+// entries do not fit the LDS: thousands of spheres): the cells' runs follow each other in MORTON order of their
+// cells instead of x-fastest (the cell record is `first | count`, so placement is free and the walk's linear cell
+// index stays), so the rays of neighbouring lanes, which stand in neighbouring cells, share cache lines in all
+// three axes: config 5 -0.7 % (118.2-118.6 against 119.3 ms).  Measured beside it and NOT used: every run padded
+// to four entries on a 64-byte boundary, so that a leaf round reads one aligned piece of one line per lane — +2.5 %
+// (122.0-122.6 ms): the padding grows the array by 60 % and with it the misses of the 32 KB vector L1, which costs
+// more than the straddled lines did (tools/sweep_knobs.py PT_PAD_RUNS, docs/HISTORY.md round 4).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -321,6 +330,58 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     return true;
   }
   return false;
+}
+
+// interleave the low 10 bits of x, y, z (cells per axis <= kMaxAxis = 1023)
+inline uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+  auto spread = [](uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+  };
+  return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+// The layout for entries gathered from global memory (see the header comment): the cells' runs in Morton order
+// of their cells (`pad`: also padded to four entries — measured, not used); the always-tested group follows as
+// before.  Which spheres a cell holds, and in which order, does not change — only where its run lies.  Returns
+// false (and leaves the grid as it was) when the array would not fit the 24-bit entry field.
+inline bool morton_runs(Grid* g, bool pad = false, bool morton = true) {
+  const size_t n_cells = g->cells.size();
+  std::vector<uint32_t> order;
+  order.reserve(g->nonempty);
+  size_t padded = 0;
+  for (size_t c = 0; c < n_cells; c++) {
+    const uint32_t cnt = g->cells[c] >> 24;
+    if (cnt) { order.push_back((uint32_t)c); padded += pad ? ((cnt + 3u) & ~3u) : cnt; }
+  }
+  const size_t n_tail = (size_t)g->n_entries - g->n_cell_entries;  // the always-tested group, padded to four already
+  if (padded + n_tail >= (1u << 24) - 8u) return false;
+  const uint32_t nx = g->n[0], ny = g->n[1];
+  auto key = [&](uint32_t c) { return morton3(c % nx, (c / nx) % ny, c / (nx * ny)); };
+  if (morton) std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+  std::vector<float> entries((padded + n_tail) * 4);
+  std::vector<uint32_t> index(padded + n_tail, 0xffffffffu);
+  const float never[4] = {0.f, 0.f, 0.f, -std::numeric_limits<float>::infinity()};
+  for (size_t e = 0; e < padded; e++) std::memcpy(&entries[4 * e], never, 16);
+  uint32_t first = 0;
+  for (uint32_t c : order) {
+    const uint32_t old = g->cells[c] & 0xffffffu, cnt = g->cells[c] >> 24;
+    std::memcpy(&entries[4 * (size_t)first], &g->entries[4 * (size_t)old], (size_t)cnt * 16);
+    std::memcpy(&index[first], &g->entry_index[old], (size_t)cnt * 4);
+    g->cells[c] = first | (cnt << 24);
+    first += pad ? ((cnt + 3u) & ~3u) : cnt;
+  }
+  std::memcpy(&entries[4 * padded], &g->entries[4 * (size_t)g->n_cell_entries], n_tail * 16);
+  std::memcpy(&index[padded], &g->entry_index[g->n_cell_entries], n_tail * 4);
+  g->entries.swap(entries);
+  g->entry_index.swap(index);
+  g->n_cell_entries = (uint32_t)padded;
+  g->n_entries = (uint32_t)(padded + n_tail);
+  return true;
 }
 
 }  // namespace ptgrid

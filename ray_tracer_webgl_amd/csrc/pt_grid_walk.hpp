@@ -48,7 +48,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     for (unsigned long long m_x = pt_ballot(mask != 0u); m_x != 0ull; m_x = pt_ballot(mask != 0u)) {
       tally.exact(m_x);
       if (mask != 0u) {
-        const uint32_t k = (uint32_t)__builtin_ctz(mask);
+        const uint32_t k = first_candidate(mask);
         mask &= mask - 1u;
         const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
         const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));
@@ -101,6 +101,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     }
   }
 
+  tally.phase(2);
   // per-ray constants of the walk (recomputed for carried lanes: cheaper than keeping them)
   const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f);
   const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f);
@@ -172,7 +173,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     }
   }
 
-  tally.phase(2);
+  tally.phase(3);
   uint32_t walk_iters = 0;
   const uint32_t carry_base = A.carry_lanes, carry_slope = A.carry_lanes != 0u ? 4u : 0u; // (0: nobody is left behind)
   const uint32_t half_live = ((uint32_t)n_live + 1u) >> 1;
@@ -205,7 +206,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       }
       m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
     }
-    tally.phase(3);
+    tally.phase(4);
     const bool has = (pend >> 24) != 0u;
     const unsigned long long m_has = pt_ballot(has);
     if (m_has == 0ull) break; // no cell under test and nobody can move: every walk is over
@@ -229,7 +230,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       // the cell is done: can anything registered only in later cells still win?
       rem = (has && pend < 0x1000000u && closest < t_exit) ? 0u : rem;
     }
-    tally.phase(4);
+    tally.phase(5);
     walk_iters++;
     const uint32_t n_on = (uint32_t)__popcll(pt_ballot(rem != 0u) | pt_ballot(pend >= 0x1000000u));
     // The loop ends when nobody walks any more — or with a few stragglers left, which are carried: the

@@ -127,7 +127,7 @@ static pt::Sphere from_host(const PtHostSphere& h) {
 }
 
 // the hierarchy of PT_GEOM_BVH exactly as pt_set_spheres (pt_api.hip) builds and uploads it
-PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
+static int build_grid_export(bool runs, const PtSphere* s, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
                          float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
                          uint32_t* entry_index, size_t n_index) {
   if (!s && n) return PT_ERR_INVALID;
@@ -144,6 +144,7 @@ PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float
   }
   ptgrid::Grid g;
   if (!regular || !ptgrid::build(geom.data(), radii.data(), n, &g)) return PT_ERR_NOT_READY;
+  if (runs && !ptgrid::morton_runs(&g)) return PT_ERR_CAPACITY;
   if (counts8) {
     counts8[0] = g.n[0]; counts8[1] = g.n[1]; counts8[2] = g.n[2]; counts8[3] = g.n_cell_entries;
     counts8[4] = g.n_always; counts8[5] = g.n_entries; counts8[6] = g.max_cell_entries; counts8[7] = g.nonempty;
@@ -159,6 +160,19 @@ PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float
   if (entries) std::copy(g.entries.begin(), g.entries.end(), entries);
   if (entry_index) std::copy(g.entry_index.begin(), g.entry_index.end(), entry_index);
   return PT_OK;
+}
+
+PT_API int pt_build_grid(const PtSphere* s, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
+                         float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
+                         uint32_t* entry_index, size_t n_index) {
+  return build_grid_export(false, s, n, counts8, geom12, margin4, delta_g, cells, n_cells, entries, entry_floats, entry_index, n_index);
+}
+// include/ptrace_dev.h: the same grid in the layout the kernels use when the entries are gathered from
+// global memory (ptgrid::morton_runs: the cells' runs in Morton order of their cells)
+PT_API int pt_build_grid_runs(const PtSphere* s, uint32_t n, uint32_t* counts8, float* geom12, float* margin4,
+                              float* delta_g, uint32_t* cells, size_t n_cells, float* entries, size_t entry_floats,
+                              uint32_t* entry_index, size_t n_index) {
+  return build_grid_export(true, s, n, counts8, geom12, margin4, delta_g, cells, n_cells, entries, entry_floats, entry_index, n_index);
 }
 
 // The numbers the grid kernels' ENTRY test and cell look-up use beside geom12 / margin4 of

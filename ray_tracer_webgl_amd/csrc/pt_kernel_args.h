@@ -92,14 +92,14 @@ struct PtKernelArgs {
                                    // hipGraph advance it on the device); points at a zero cell otherwise.  Never NULL.
 };
 
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.
 #define PT_LDS_ENTRIES(n) ((((n) + 7u) & ~7u) + 4u)
 #define PT_MAX_SPHERES_SMALL 16u   // PT_GEOM_SMALL: the whole list reaches the VALU from SGPRs, four spheres per s_load_dwordx16
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
-#define PT_PARK_DWORDS 14u  // per-lane path state parked in LDS during the hierarchy walk
+#define PT_PARK_DWORDS 14u  // per-lane path state parked in LDS during the walks
 #define PT_PARK_STRIDE 15u  // dwords per lane in the parking area (odd: conflict-free columns)
 #define PT_BVH_LDS_BYTES32(n_nodes, n_slots) ((((size_t)(n_nodes) + 1u) * 2u + (size_t)(n_slots)) * 16u)
 #define PT_BVH_LDS_BYTES16(n_nodes) (((size_t)(n_nodes) + 1u) * 16u)

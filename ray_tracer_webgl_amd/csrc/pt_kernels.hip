@@ -32,106 +32,7 @@
 // ARITHMETIC: PT-SPEC — the same contract the CPU oracle states independently in
 // oracle/pt_oracle.c.  Compiled with -ffp-contract=off; every fused multiply-add is an explicit
 // __builtin_fmaf.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "pt_kernel_args.h"
-#include "pt_arith.hpp"
-#include "pt_scene.hpp"
-#include "pt_refill.hpp"
-#include "pt_list.hpp"
-#include "pt_bvh_walk.hpp"
-#include "pt_grid_walk.hpp"
-#include "pt_shade.hpp"
-
-using namespace ptd;
-
-// --------------------------------------------------------------------------------------------
-// The path-tracing kernel body: one persistent wave working through (pixel, pass) items.
-// Template parameters: pt_scene.hpp `Scene`; COUNT = the measuring twin (tallies live); RR = the
-// opt-in Russian-roulette build (pt_shade.hpp).
-// --------------------------------------------------------------------------------------------
-template <bool SCAN_LDS, bool HAVE_LDS, int WALK = 0, bool COUNT = false, bool RR = false>
-__device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
-  using namespace ptk;
-  using S = Scene<SCAN_LDS, HAVE_LDS, WALK>;
-  S::stage(A);
-
-  Path p;           // per lane
-  Queue q;          // wave-uniform
-  Carry cw;         // walk kernels: what survives a wave step
-  BvhWalk bw;
-  GridWalk gw;
-  Tally<COUNT> tally;
-  const PixelDiv pd = pixel_div();
-  uint32_t seg_count = 0; // wave-uniform tally (samples are derived on the host: pixels * spp * passes)
-  tally.start();
-
-  for (;;) {
-    refill<COUNT>(A, p, q, pd, tally);
-    tally.phase(0);
-    // one copy of the camera-ray code per step serves both kinds of lanes: those that just
-    // pulled an item and those whose previous path ended in the last step
-    if (p.alive && p.new_path) {
-      start_sample(p, pd);
-      p.new_path = false;
-    }
-    tally.phase(1);
-    const unsigned long long live = pt_ballot(p.alive);
-    if (live == 0ull) break; // every lane is exhausted: the queue is dry
-    tally.step();
-
-    // ---- hit_world: static/shader.frag:175-196 -------------------------------------------------
-    Hit h;
-    if constexpr (S::TREE) h.closest = cw.carried ? cw.closest_w : PT_MAX_T;
-    if (!cw.carried) cw.hit_pos = 0xffffffffu;
-    const bool fast = regular_ray(A, p);
-    const int n_live = (int)__popcll(live);
-    if constexpr (S::TREE) park_store(A, p);
-    const bool coop = (n_live <= (int)A.coop_max_live) && (pt_ballot(p.alive && !fast) == 0ull) &&
-                      (pt_ballot(cw.carried) == 0ull);
-    if (coop) {
-      tail_mode<S>(A, p, live, h);
-    } else {
-      h.lit_from = fast ? 0xffffffffu : 0u;
-      const bool scan_lane = p.alive && fast;
-      if constexpr (S::BVH) bvh_walk<S, COUNT>(A, p, scan_lane, n_live, cw, bw, h, tally);
-      else if constexpr (S::GRID) grid_walk<S, COUNT>(A, p, scan_lane, n_live, cw, gw, h, tally);
-      else if constexpr (S::SMALL) small_scan<S>(A, p, scan_lane, h);
-      else list_scan<S>(A, p, scan_lane, h);
-      tally.literal(A, p.alive && !fast, scan_lane && h.lit_from < A.n_spheres, p.slab_index);
-      // a REGULAR ray the grid walk hands over whole (it starts far outside the scene and reaches the
-      // grid: pt_grid_walk.hpp) is looked at by the whole wave, 64 spheres at a time, like the rays of
-      // tail mode, where the list is long (the kernels whose entries do not fit the LDS: thousands of
-      // spheres, 0.3 ms per ray through the literal loop; config 5: 2.3e-5 of the rays, 1.5 % of the time)
-      if constexpr (S::GRID && S::WALK != 4) {
-        const bool handed_over = scan_lane && h.lit_from == 0u;
-        const unsigned long long m_h = pt_ballot(handed_over);
-        if (m_h != 0ull) {
-          tail_mode<S>(A, p, m_h, h);
-          if (handed_over) h.lit_from = 0xffffffffu;
-        }
-      }
-      literal_loop<S>(A, p, h); // (irregular rays; list kernels: candidates that did not fit the queue)
-    }
-    if constexpr (S::TREE) {
-      if (coop) cw.carried = false;
-      cw.closest_w = h.closest;
-      park_load(A, p);
-    }
-    tally.phase(5);
-
-    // ---- shade: static/shader.frag:304-335 (carried lanes are not there yet) --------------------
-    const bool shade = p.alive && !cw.carried;
-    seg_count += (uint32_t)__popcll(pt_ballot(shade));
-    tally.timebin(A, shade);
-    if (shade) shade_segment<S, RR>(A, p, h, cw);
-    tally.phase(6);
-  }
-
-  if (lane_id() == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
-  tally.flush(A);
-}
+#include "pt_trace_body.hpp"
 
 // blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
 // workgroup fits per CU); dynamic LDS = PT_LDS_ENTRIES(n_spheres) * 16 bytes.
@@ -184,46 +85,6 @@ extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem(const PtKernelArgs A) {
   pt_trace_body<false, false, 6>(A);
 }
-// measuring twins (PT_OPT_COUNT_WORK): the same walks with the executed-work tallies
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh_count(const PtKernelArgs A) {
-  pt_trace_body<false, false, 1, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_count(const PtKernelArgs A) {
-  pt_trace_body<false, false, 4, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells_count(const PtKernelArgs A) {
-  pt_trace_body<false, false, 5, true>(A);
-}
-
-// Russian-roulette builds (PT_OPT_RUSSIAN_ROULETTE, opt-in; same launch shapes as their namesakes)
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_rr(const PtKernelArgs A) {
-  pt_trace_body<false, true, 7, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_rr(const PtKernelArgs A) {
-  pt_trace_body<false, true, 0, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 0, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 1, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_nodes_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 2, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 3, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 4, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_cells_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 5, false, true>(A);
-}
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem_rr(const PtKernelArgs A) {
-  pt_trace_body<false, false, 6, false, true>(A);
-}
-
 // --------------------------------------------------------------------------------------------
 // Work-queue order for the NEXT launch: tiles sorted by the segment count of their HEAVIEST
 // item in the previous launch (pass 0), largest first.  A short launch cannot end before its

@@ -225,7 +225,7 @@ __device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p,
       for (;;) {
         if (pt_ballot(mask != 0u) == 0ull) break;
         if (mask != 0u) {
-          const uint32_t k = (uint32_t)__builtin_ctz(mask); // ascending list order
+          const uint32_t k = first_candidate(mask); // ascending list order
           mask &= mask - 1u;
           const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
           const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));

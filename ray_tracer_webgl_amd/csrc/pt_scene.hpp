@@ -236,8 +236,9 @@ struct Tally {
   uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
            n_carried = 0;
   // phase clock (shader cycles, s_memtime): where a wave's time goes
-  //   0 refill  1 camera ray  2 set-up + always-tested  3 advance / node loops  4 leaf + exact  5 literal + rest  6 shade
-  unsigned long long ph_t[7] = {0, 0, 0, 0, 0, 0, 0}, ph_mark = 0;
+  //   0 refill  1 camera ray  2 always-tested spheres (hierarchy: set-up + outliers)  3 per-ray constants + grid entry
+  //   4 advance / node loops  5 leaf + exact  6 literal + parking + the rest  7 shade
+  unsigned long long ph_t[PT_N_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_mark = 0;
 
   __device__ __forceinline__ void start() {
     if constexpr (COUNT) {
@@ -294,7 +295,7 @@ struct Tally {
         atomicAdd(&A.counters[PT_CTR_WORK + 6], (unsigned long long)n_steps);
         atomicAdd(&A.counters[PT_CTR_WORK + 7], (unsigned long long)n_carried);
         if (tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
-        for (int k = 0; k < 7; k++) atomicAdd(&A.counters[PT_CTR_PHASES + k], ph_t[k]);
+        for (int k = 0; k < PT_N_PHASES; k++) atomicAdd(&A.counters[PT_CTR_PHASES + k], ph_t[k]);
         if (A.wave_log) {
           unsigned long long* wl = A.wave_log + 3ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
           wl[0] = t_wave_start; wl[1] = t_wave_dry; wl[2] = __builtin_amdgcn_s_memrealtime();
@@ -303,6 +304,18 @@ struct Tally {
     }
   }
 };
+
+// The lowest set bit of a 4-bit candidate mask (the exact loops of pt_grid_walk.hpp and pt_list.hpp small_scan).
+// TOTAL on purpose: __builtin_ctz(0) is undefined, and what gfx950 makes of it (v_ffbl_b32 -> 0xffffffff) turned a
+// harmless-looking refactoring of the grid walk's exact loop into a wild read in round 3: with the loop's
+// `if (mask != 0u)` region removed, an idle lane computed the slot `base + 0xffffffff`, and lanes without a cell
+// under test (base 0) indexed bvh_slot_index[] 16 GiB out of bounds on their first tie.  With the
+// fifth bit set the answer for an empty mask is 4 — a slot inside the four entries of slack every entry array
+// carries — at the price of one v_or_b32 per evaluation (A/B on one device: +0.2 % on config 2,
+// inside the noise on configs 4 and 5).
+__device__ __forceinline__ uint32_t first_candidate(uint32_t mask) {
+  return (uint32_t)__builtin_ctz(mask | 16u);
+}
 
 // The literal cheap half of hit_sphere, static/shader.frag:146-152: oc, half_b, c, discriminant, in the
 // PT-SPEC operation order (the one expression every phase that looks at a sphere evaluates, so a

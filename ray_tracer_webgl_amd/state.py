@@ -18,6 +18,7 @@ class State:
         rc = self.lib.pt_state_create(C.byref(self._h), int(width), int(height))
         if rc != 0:
             raise ValueError("pt_state_create failed: %d" % rc)
+        self.keys = 0  # the KeydownMap as last set through set_keys (abi.KEY_* mask)
 
     def close(self):
         if self._h:
@@ -61,6 +62,7 @@ class State:
 
     def set_keys(self, mask):
         self._ok(self.lib.pt_state_set_keys(self._h, int(mask)))
+        self.keys = int(mask)
 
     # src/state.rs:411-450
     def update_position(self, dt_ms):

@@ -40,7 +40,12 @@ class PathTracer:
             import torch
 
             self._torch = torch
-            stream = torch.cuda.current_stream(self.device)
+            try:
+                stream = torch.cuda.current_stream(self.device)
+            except RuntimeError as e:  # e.g. "No HIP GPUs are available": a second HIP runtime in this process (_lib.py)
+                self.close()
+                raise PtError(abi.PT_ERR_NO_DEVICE, "PyTorch cannot see the GPU libptrace is using (%s): two HIP runtimes in one "
+                              "process?  `import torch` before anything of ray_tracer_webgl_amd" % e) from e
             # torch's default stream is the NULL stream, and NULL means "the context's own stream" in this
             # ABI: name it as hipStreamLegacy (1).  Kernels must run on the stream torch orders its own work
             # on, or a gather / .cpu() right after render_passes reads the buffer before they have written it.
@@ -146,6 +151,16 @@ class PathTracer:
 
     def synchronize(self):
         self._check(self.lib.pt_synchronize(self._ctx))
+
+    def wait(self, timeout_s):
+        """Dev tools' watchdog (include/ptrace_dev.h pt_debug_wait): True when the stream went idle within
+        timeout_s, False on timeout.  Polls an event, never blocks in the driver."""
+        fn = self.lib.pt_debug_wait
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_uint]
+        rc = fn(self._ctx, int(timeout_s * 1000))
+        if rc < 0:
+            raise PtError(rc, "pt_debug_wait failed")
+        return rc == 0
 
     # -- the reference's frame on device-resident textures ---------------------------------------
     def clear_textures(self):

@@ -24,23 +24,29 @@ MIN_T = np.float32(0.001)
 MAX_T = np.float32(1e5)
 
 
-def build(spheres):
+def build(spheres, runs=False):
+    """runs=True: the layout of the kernels that gather entries from global memory (pt_build_grid_runs,
+    include/ptrace_dev.h: the cells' runs in Morton order of their cells)"""
     lib = _lib.load()
+    build_fn = lib.pt_build_grid
+    if runs:
+        build_fn = lib.pt_build_grid_runs
+        build_fn.restype, build_fn.argtypes = lib.pt_build_grid.restype, lib.pt_build_grid.argtypes
     ptr, n, keep = abi.spheres_as_ctypes(spheres)
     counts = np.zeros(8, np.uint32)
     geom = np.zeros(12, np.float32)
     margin = np.zeros(4, np.float32)
     dg = C.c_float(0)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = lib.pt_build_grid(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), None, 0, None, 0, None, 0)
+    rc = build_fn(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), None, 0, None, 0, None, 0)
     if rc != 0:
         return rc, None
     nc = int(counts[0]) * int(counts[1]) * int(counts[2])
     cells = np.zeros(nc, np.uint32)
     entries = np.zeros((counts[5], 4), np.float32)
     index = np.zeros(counts[5], np.uint32)
-    rc = lib.pt_build_grid(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), vp(cells), cells.size, vp(entries),
-                           entries.size, vp(index), index.size)
+    rc = build_fn(ptr, n, vp(counts), vp(geom), vp(margin), C.byref(dg), vp(cells), cells.size, vp(entries),
+                  entries.size, vp(index), index.size)
     consts = np.zeros(10, np.float32)  # what pt_render_passes copies into the launch arguments
     assert lib.pt_grid_walk_constants(ptr, n, vp(consts)) == 0
     return rc, dict(r2_near=consts[0], lo_n=consts[1:4].copy(), hi_n=consts[4:7].copy(), inv_h=consts[7:10].copy(),
@@ -347,3 +353,43 @@ def test_walk_returns_the_pair_hit_world_returns(name):
     if len(sph) >= 100 and name != "clumps":
         assert total_looked < 0.1 * 4 * n_rays * len(sph)
     assert total_lit < 0.2 * 4 * n_rays
+
+
+def _morton(x, y, z):
+    k = 0
+    for b in range(10):
+        k |= ((int(x) >> b) & 1) << (3 * b) | ((int(y) >> b) & 1) << (3 * b + 1) | ((int(z) >> b) & 1) << (3 * b + 2)
+    return k
+
+
+@pytest.mark.parametrize("name", ["field300", "config2", "clumps", "flat", "config5"])
+def test_morton_runs_hold_the_same_spheres_in_the_same_order(name):
+    """The layout for entries gathered from global memory (csrc/pt_grid.hpp morton_runs; config 5's kernel)
+    only MOVES the runs: every cell keeps its spheres in their order, the runs follow each other in Morton
+    order of their cells without gaps or overlaps, and the always-tested group still follows the cells'
+    entries."""
+    sph = GRID_SCENES[name]()
+    rc, g = build(sph)
+    rc2, r = build(sph, runs=True)
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(g["n"], r["n"]) and g["n_always"] == r["n_always"] and g["nonempty"] == r["nonempty"]
+    assert g["n_cell_entries"] == r["n_cell_entries"] and g["n_entries"] == r["n_entries"]
+    cnt_g, cnt_r = g["cells"] >> 24, r["cells"] >> 24
+    assert np.array_equal(cnt_g, cnt_r)
+    first_g, first_r = g["cells"] & 0xFFFFFF, r["cells"] & 0xFFFFFF
+    used = np.zeros(r["n_cell_entries"], bool)
+    nx, ny = int(g["n"][0]), int(g["n"][1])
+    keys = []
+    for c in np.nonzero(cnt_r)[0]:
+        a, b, k = int(first_g[c]), int(first_r[c]), int(cnt_r[c])
+        assert np.array_equal(g["index"][a:a + k], r["index"][b:b + k])
+        assert np.array_equal(g["entries"][a:a + k].view(np.uint32), r["entries"][b:b + k].view(np.uint32))
+        assert not used[b:b + k].any()
+        used[b:b + k] = True
+        keys.append((b, _morton(c % nx, (c // nx) % ny, c // (nx * ny))))
+    assert used.all()
+    keys.sort()
+    assert all(k0[1] < k1[1] for k0, k1 in zip(keys, keys[1:])), "runs are not in Morton order of their cells"
+    # the always-tested group: unchanged, behind the cells' entries
+    assert np.array_equal(g["index"][g["n_cell_entries"]:], r["index"][r["n_cell_entries"]:])
+    assert np.array_equal(g["entries"][g["n_cell_entries"]:].view(np.uint32), r["entries"][r["n_cell_entries"]:].view(np.uint32))

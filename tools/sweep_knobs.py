@@ -1,5 +1,5 @@
 """Dev tool: one-variable sweeps of the scheduling knobs on config 2's timed launch (grid walk, 64 x 16 spp),
-each point in a fresh child process on the PT_DEV_KNOBS build (ray_tracer_webgl_amd/libptrace_knobs.so)."""
+each point in a fresh child process on the PT_DEV_KNOBS build (build_ab/libptrace_knobs.so)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,14 +20,17 @@ def child():
     pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(n)
     ms = []
     for rep in range(4):
-        pt.reset(); pt.render_passes(n); ms.append(pt.stats().render_kernel_ms)
+        pt.reset(); pt.render_passes(n)
+        if not pt.wait(float(os.environ.get("AB_DEADLINE_S", "60"))):  # watchdog: poll with a deadline, never block in the driver
+            print("WATCHDOG: launch did not finish", file=sys.stderr, flush=True); os._exit(3)
+        ms.append(pt.stats().render_kernel_ms)
     print("%.3f" % min(ms[1:]), flush=True)
     pt.close()
 
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     child()
 else:
-    lib = os.path.join(ROOT, "ray_tracer_webgl_amd", "libptrace_knobs.so")
+    lib = os.environ.get("PT_KNOBS_LIB") or os.path.join(ROOT, "build_ab", "libptrace_knobs.so")  # make -C ray_tracer_webgl_amd/csrc variant NAME=knobs DEFS=-DPT_DEV_KNOBS
     points = [("base", {})] + [("carry %d" % v, {"SW_CARRY": str(v)}) for v in (6, 8, 10, 16, 20)] + \
              [("refill_min %d" % v, {"SW_REFILL": str(v)}) for v in (1, 2, 6, 8)] + \
              [("block %d" % v, {"PT_BVH_BLOCK": str(v)}) for v in (256, 1024)] + \
@@ -41,3 +44,5 @@ else:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, PT_LIB=lib, **env),
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         print("%-16s %s" % (name, out.stdout.strip() or ("FAILED " + out.stderr[-300:])), flush=True)
+        if out.returncode == 3:  # the watchdog fired: no further GPU work behind a kernel that may never end
+            raise SystemExit(3)

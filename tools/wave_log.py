@@ -1,6 +1,7 @@
 """Dev tool: when do the waves of a launch start, see the queue dry, and end?  (measuring twin)
 
-    python tools/wave_log.py [ranks] [passes] [spp]      (WL_CONFIG=config5: that scene; WL_DECO=1: decorrelated pass times)
+    python tools/wave_log.py [ranks] [passes] [spp]      (WL_CONFIG=config5 / config4 / default: that scene — the last two through
+                                                          the small-list kernel's twin; WL_DECO=1: decorrelated pass times)
 """
 import ctypes as C
 import os
@@ -15,16 +16,24 @@ from ray_tracer_webgl_amd.tracer import PathTracer  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-sc = (scenes.config5 if os.environ.get("WL_CONFIG") == "config5" else scenes.config2)(1920, 1080, spp, passes, 50)
+which = os.environ.get("WL_CONFIG", "config2")
+if which == "config4":      # the closed room through the small-list kernel's twin
+    sc = scenes.config4(1024, 1024, spp, passes, 50)
+elif which == "default":    # State::default at the reference's own size
+    sc = scenes.default_scene(1280, 702, spp, 8, passes)
+else:
+    sc = (scenes.config5 if which == "config5" else scenes.config2)(1920, 1080, spp, passes, 50)
+W, H = sc.params.width, sc.params.height
+path = abi.PT_GEOM_SMALL if which in ("config4", "default") else abi.PT_GEOM_GRID
 if os.environ.get("WL_DECO"):
     sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
 p = sc.params.copy()
 p.band_rows, p.band_index, p.band_count = ptdist.band_of(0, n, 4)
-pt = PathTracer(1920, 1080)
+pt = PathTracer(W, H)
 pt.set_spheres(sc.spheres)
 pt.set_params(p)
 pt.reserve_passes(passes)
-pt.set_geometry_path(abi.PT_GEOM_GRID)
+pt.set_geometry_path(path)
 for _ in range(2):
     pt.reset()
     pt.render_passes(passes)
@@ -56,8 +65,8 @@ first = int((buf[:k, 0].min() >> np.uint64(16)) & np.uint64(63))
 order = [(first + j) % 64 for j in range(64)]
 print("  segments per 0.655 ms bin from the first wave's start (Gray/s):")
 print("   " + " ".join("%.1f" % (bins[b] / 0.65536e-3 / 1e9) for b in order if bins[b] > 0))
-ph = ctr[24:31].astype(np.float64)
-names = ["refill", "camera ray", "set-up + always-tested", "advance / node loops", "leaf + exact", "literal + unpark", "shade"]
+ph = ctr[24:32].astype(np.float64)
+names = ["refill", "camera ray", "park + always-tested", "per-ray constants + entry", "advance / node loops", "leaf + exact", "literal + unpark", "shade"]
 print("  wave-time shares by phase (s_memtime): " + ", ".join("%s %.3f" % (n_, v / ph.sum()) for n_, v in zip(names, ph)))
 lit = ctr[16:21]
 print("  PHASE 3 (literal loop): %d irregular lane-steps, %d handed over by the walk, %d wave steps; last irregular pixel (slab index) %d, last handed-over %d"
