@@ -207,6 +207,26 @@ def test_bench_two_ranks_on_one_device():
     assert d["value"] > 0 and d["segments"] > 0 and d["first_frame_ms"] > 0
 
 
+def test_bench_under_the_drivers_flags_still_carries_its_verdicts():
+    """The driver runs `bench.py --steps 20 --warmup 5` (1280 spp: not the committed 1024-spp frame), at N = 1
+    and — on an 8-GPU node — under torchrun with the same flags.  The line must verify itself anyway: every
+    rank renders the committed workload once more after the timed region, through the same partition and the
+    same gather, and rank 0 hashes that (`gather_matches_single_gpu` true, never null); the measuring twin is
+    compared with a launch of the timed kernel over the same passes.  Two self-started ranks on one device
+    (gloo collectives), then one rank."""
+    d = _bench("--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "20", "--warmup", "5",
+               "--no-cpu-baseline", "--no-list-walk", "--no-work-count", "--no-first-frame", "--no-weak-series")
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    gc = d["gather_check"]
+    assert d["gather_matches_single_gpu"] is True and gc["segments_match"] is True, gc
+    assert "rendered again after the timed region" in gc["frame"]
+    assert abs(d["sec_to_converged_frame"] - d["ms_per_step"] * 16 / 1e3) < 1e-3  # still quoted on the 1024-spp frame
+    d = _bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-list-walk", "--no-first-frame")
+    assert d["n_gpus"] == 1 and d["gather_matches_single_gpu"] is True, d["gather_check"]
+    assert d["roofline"]["executed"]["twin_segments_equal_timed_kernel"] is True
+    assert d["roofline"]["counters"] is None or d["roofline"]["counters"]["valu_issue_frac"] > 0
+
+
 def test_bench_rccl_path_with_one_rank():
     """--force-dist: the RCCL code path (init with device_id, all_gather_into_tensor on device buffers,
     all_reduce of the timings) as far as one GPU allows.  Rank 0's stdout must carry the JSON line and
@@ -253,6 +273,9 @@ def test_bench_lines_of_the_stress_configs(config, kernels):
         assert d["list_walk"]["roofline_frac"] > 0
     if r["kernel"] != "pt_trace_kernel_bvh_nodes":  # (that build has no measuring twin)
         assert r["frac"] and 0 < r["frac"] <= 1
+    if config == "4":  # list kernels: the algorithmic tests AND the per-segment shade / RNG / camera term
+        pp = r["per_pass"]
+        assert pp["executed_flop"] > pp["algorithmic_flop"] and abs(pp["executed_flop"] - pp["algorithmic_flop"] - 150 * pp["segments"]) < 1e-3 * pp["executed_flop"]
 
 
 @pytest.mark.parametrize("config", ["4", "5"])
