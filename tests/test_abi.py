@@ -229,3 +229,27 @@ def test_rust_binding_lists_the_render_abi():
         return len(re.findall(r"pub \w+:", body))
     assert c_fields("PtSphere") == rust_fields("PtSphere")
     assert c_fields("PtParams") == rust_fields("PtParams")
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """libptrace.so needs libamdhip64.so.7 and PyTorch ships its own copy.  Loaded in the order libptrace ->
+    torch the process would hold two HIP runtimes, and the second one to touch the GPU finds none (seen on the
+    GPU box as "No HIP GPUs are available" from PathTracer(use_torch=True)).  _lib.load() loads PyTorch's copy
+    first when PyTorch is installed but not imported yet: one runtime mapped either way (no GPU needed to see
+    which libraries the loader mapped)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ray_tracer_webgl_amd import _lib\n"
+        "_lib.load()\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch\n"
+        "libs = sorted({ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64' in ln})\n"
+        "print(len(libs), libs)\n"
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[0] == "1", r.stdout

@@ -288,3 +288,26 @@ def test_bench_stress_config_frames_match_the_committed_digests(config):
     assert d["gather_matches_single_gpu"] is True, d["gather_check"]
     assert d["gather_check"]["segments_match"] is True
     assert d["converged_frame_spp"] == {"4": 8192, "5": 256}[config]
+
+
+def test_the_dev_tools_watchdog_polls_instead_of_blocking():
+    """pt_debug_wait (include/ptrace_dev.h): records an event behind what is enqueued and polls it with a
+    deadline.  An idle stream answers at once; a launch in flight is waited for (well inside the deadline);
+    a zero deadline on a long launch reports "timeout" without blocking — and the launch still finishes."""
+    import time
+
+    sc = scenes.config2(1920, 1080, 16, 16, 50)
+    t = PathTracer(1920, 1080)
+    t.set_geometry_path(abi.PT_GEOM_GRID)
+    t.set_spheres(sc.spheres)
+    t.set_params(sc.params)
+    t.reserve_passes(16)
+    assert t.wait(1.0) is True            # nothing enqueued
+    t.render_passes(16)                   # ~28 ms of kernel time
+    t0 = time.perf_counter()
+    timed_out = not t.wait(0.0)
+    assert time.perf_counter() - t0 < 0.02   # did not block on the launch
+    assert t.wait(30.0) is True
+    st = t.stats()
+    assert st.segments > 0 and (timed_out or st.render_kernel_ms > 0)
+    t.close()

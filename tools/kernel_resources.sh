@@ -1,14 +1,18 @@
 #!/bin/bash
 # Compact per-kernel resource table (VGPRs, SGPRs, spills, scratch, waves/SIMD) + static instruction
-# counts of the kernels, from a cross-compile of pt_kernels.hip for gfx950 (no GPU needed).
+# counts of the kernels, from a cross-compile of both device translation units (pt_kernels.hip: what every
+# context uses; pt_kernels_extra.hip: Russian-roulette builds, measuring twins) for gfx950 (no GPU needed).
 # Usage: tools/kernel_resources.sh [outdir]   (default /tmp/ptres)
 set -e
 OUT=${1:-/tmp/ptres}
 mkdir -p "$OUT"
 cd "$(dirname "$(readlink -f "$0")")/../ray_tracer_webgl_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize \
-  -fvisibility=hidden -Wall -Wno-unused-function $PT_EXTRA_FLAGS -Rpass-analysis=kernel-resource-usage \
-  -save-temps=obj -c pt_kernels.hip -o "$OUT/pt_kernels.o" 2> "$OUT/remarks.txt" || { cat "$OUT/remarks.txt"; exit 1; }
+: > "$OUT/remarks.txt"
+for TU in pt_kernels pt_kernels_extra; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize \
+    -fvisibility=hidden -Wall -Wno-unused-function $PT_EXTRA_FLAGS -Rpass-analysis=kernel-resource-usage \
+    -save-temps=obj -c $TU.hip -o "$OUT/$TU.o" 2>> "$OUT/remarks.txt" || { cat "$OUT/remarks.txt"; exit 1; }
+done
 grep -v "remark:" "$OUT/remarks.txt" | grep -E "warning|error" || true
 python3 - "$OUT" <<'PY'
 import re, sys, glob
@@ -22,9 +26,9 @@ for blk in txt.split("Function Name: ")[1:]:
                  g("SGPRs Spill").group(1), g(r"ScratchSize \[bytes/lane\]").group(1), g(r"Occupancy \[waves/SIMD\]").group(1)))
 asm = glob.glob(out + "/*gfx950*.s")
 counts = {}
-if asm:
+for path in asm:
     cur = None
-    for line in open(asm[0]):
+    for line in open(path):
         m = re.match(r"^(\w+):\s*(;.*)?$", line)
         if m and m.group(1).startswith("pt_"):
             cur = m.group(1); counts[cur] = [0, 0, 0, 0]; continue
