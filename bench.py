@@ -452,7 +452,8 @@ def main():
         # algorithmic HBM bytes per pass of the trace kernel: one 16-B slab store per (pixel, pass)
         # item (+ the scene once per launch, 48 B/sphere); the fold kernel's traffic is separate
         hbm_bytes_per_pass = local_pix * 16 + n_sph * 48 / max(ppl, 1)
-        kernel_name = {abi.PT_GEOM_LDS: "pt_trace_kernel", abi.PT_GEOM_SCALAR: "pt_trace_kernel_scalar", abi.PT_GEOM_SMALL: "pt_trace_kernel_small",
+        kernel_name = {abi.PT_GEOM_LDS: "pt_trace_kernel", abi.PT_GEOM_SCALAR: "pt_trace_kernel_scalar",
+                       abi.PT_GEOM_SMALL: "pt_trace_kernel_small_t%d" % (n_sph % 4),  # one build per list length modulo four (pt_kernels_small.hip)
                        abi.PT_GEOM_BVH: "pt_trace_kernel_bvh", abi.PT_GEOM_GRID: "pt_trace_kernel_grid"}.get(st.geometry_path, "?")
         # which build of a walk kernel: everything staged in the LDS, the nodes / cell records only, or nothing
         # (pt_api.hip bind_hierarchy / bind_grid: what fits beside a 1024-thread workgroup's 60 KiB of parked state)

@@ -7,6 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "${PT_COLLECT_MAIN:-1}" = "1" ]; then
 BENCH="python3 bench.py --no-cpu-baseline --no-work-count"   # the default workload (config 2, 16 steps = 1024 spp); keeps the list-walk leg: the scalar list kernel is in the same trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
 # the other BASELINE configs (one launch each after pt_tune): kernel trace only
@@ -25,6 +26,7 @@ for grp in \
 done
 python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+fi  # PT_COLLECT_MAIN=0 skips the config-2 part (PT_COLLECT_CONFIGS="4" re-collects one config)
 # the other BASELINE configs through the same bench line, each with its own kernel trace and PMC passes: the records
 # bench.py attaches to `--config 3 / 4 / 5` lines (profiles/summarize.py --merge <dirs> writes profiles/pmc_traffic.json)
 for CFG in ${PT_COLLECT_CONFIGS:-3 4 5}; do

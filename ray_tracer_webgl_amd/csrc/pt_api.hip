@@ -7,7 +7,7 @@
 // (graph-capturable once pt_reserve_passes has sized the workspace); no CPU fallback exists.
 #include <hip/hip_runtime.h>
 
-#include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -270,17 +270,18 @@ constexpr size_t walk_lds_room() { return kWalkLdsMax - (size_t)PT_PARK_STRIDE *
 #define PT_KFN(name) reinterpret_cast<const void*>(name)
 
 // a kernel of pt_kernels_extra.hip; its first use loads that code object and lifts its dynamic-LDS limit
-const void* extra_kernel(int id) {
-  static std::atomic<bool> ready[PT_X_COUNT];
+const void* extra_kernel(int device, int id) {
+  static std::once_flag once[64][PT_X_COUNT];  // (function attributes belong to a device: the context's is current here)
   const void* k = pt_extra_kernel(id);
-  if (k && !ready[id].exchange(true)) {
-    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsMax);
-    (void)hipGetLastError();  // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
-  }
+  if (k)
+    std::call_once(once[device & 63][id], [k] {  // (every caller returns with the attribute set: no launch can overtake it)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLdsMax);
+      (void)hipGetLastError();  // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
+    });
   return k;
 }
 // the Russian-roulette build of a kernel when the option is on
-#define PT_PICK(rr, name, id) ((rr) ? extra_kernel(id) : PT_KFN(name))
+#define PT_PICK(rr, name, id) ((rr) ? extra_kernel(c->device, id) : PT_KFN(name))
 
 inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
   uint32_t g = (n + block - 1) / block;
@@ -840,7 +841,7 @@ static size_t bind_hierarchy(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& 
   const size_t need_all = PT_BVH_LDS_BYTES32(c->bvh_n_nodes, c->bvh_n_slots);
   const size_t need_nodes = PT_BVH_LDS_BYTES16(c->bvh_n_nodes);
   if (need_all <= lds_room) {
-    *kfn = c->count_work ? extra_kernel(PT_X_BVH_COUNT) : PT_PICK(rr, pt_trace_kernel_bvh, PT_X_BVH_RR);
+    *kfn = c->count_work ? extra_kernel(c->device, PT_X_BVH_COUNT) : PT_PICK(rr, pt_trace_kernel_bvh, PT_X_BVH_RR);
     return need_all;
   }
   if (need_nodes <= lds_room) {
@@ -874,11 +875,11 @@ static size_t bind_grid(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& A, co
   const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
   const size_t need_all = need_cells + (size_t)g.n_entries * 16;
   if (need_all <= lds_room) {
-    *kfn = c->count_work ? extra_kernel(PT_X_GRID_COUNT) : PT_PICK(rr, pt_trace_kernel_grid, PT_X_GRID_RR);
+    *kfn = c->count_work ? extra_kernel(c->device, PT_X_GRID_COUNT) : PT_PICK(rr, pt_trace_kernel_grid, PT_X_GRID_RR);
     return need_all;
   }
   if (need_cells <= lds_room) {
-    *kfn = c->count_work ? extra_kernel(PT_X_GRID_CELLS_COUNT) : PT_PICK(rr, pt_trace_kernel_grid_cells, PT_X_GRID_CELLS_RR);
+    *kfn = c->count_work ? extra_kernel(c->device, PT_X_GRID_CELLS_COUNT) : PT_PICK(rr, pt_trace_kernel_grid_cells, PT_X_GRID_CELLS_RR);
     return need_cells;
   }
   *kfn = PT_PICK(rr, pt_trace_kernel_grid_gmem, PT_X_GRID_GMEM_RR);
@@ -945,7 +946,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     // SCAN reads (their per-lane gathers — shading, tail mode — still come from the copy)
     const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
     lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
-    kfn = path == PT_GEOM_SMALL ? (c->count_work ? extra_kernel(PT_X_SMALL_COUNT) : PT_PICK(rr, pt_trace_kernel_small, PT_X_SMALL_RR))
+    kfn = path == PT_GEOM_SMALL ? (c->count_work ? extra_kernel(c->device, PT_X_SMALL_COUNT) : (rr ? extra_kernel(c->device, PT_X_SMALL_RR) : pt_small_kernel(c->n_spheres)))
           : path == PT_GEOM_LDS ? PT_KFN(pt_trace_kernel)
                                 : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar, PT_X_SCALAR_RR)
                                             : PT_PICK(rr, pt_trace_kernel_scalar_nolds, PT_X_SCALAR_NOLDS_RR));

@@ -1,4 +1,4 @@
-// pt_extra.h — the kernels of pt_kernels_extra.hip (a code object of its own), by number.
+// pt_extra.h — the kernels of pt_kernels_extra.hip and pt_kernels_small.hip (code objects of their own): how pt_api.hip reaches them.
 #pragma once
 enum {
   PT_X_BVH_COUNT = 0, PT_X_GRID_COUNT, PT_X_GRID_CELLS_COUNT, PT_X_SMALL_COUNT,
@@ -7,3 +7,5 @@ enum {
 };
 // the kernel's host-side handle (what hipLaunchKernel takes); asking for it loads nothing yet
 extern "C" const void* pt_extra_kernel(int id);
+// pt_kernels_small.hip (a code object of its own): the small-list kernel built for this list length's remainder modulo four
+extern "C" const void* pt_small_kernel(unsigned n_spheres);

@@ -78,6 +78,26 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
 
   // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is
   // padded with entries that never pass); carried lanes have done this
+#ifdef PT_ALWAYS_ONE  // dev A/B: a scene with ONE always-tested sphere (a ground: config 5) tests it alone, not beside three padding entries
+  if (A.n_outliers == 1u) {
+    const uint32_t base = n_cell_entries;
+    float4 e0;
+    if constexpr (S::WALK == 4) { e0 = S::slot_at(A, base); }
+    else { const f4v s0 = S::c_slots(A)[base]; e0 = make_float4(s0.x, s0.y, s0.z, s0.w); }
+    float hb0, cc0, ds0; sphere_test(o, d, a, e0, hb0, cc0, ds0);
+    const bool cand = fresh && pass_bit(hb0, cc0, ds0) != 0u;
+    if (pt_ballot(cand) != 0ull) {
+      tally.exact(pt_ballot(cand));
+      if (cand) {
+        const float v = hit_root(hb0, ds0, a, ya, a_guard);
+        if (!(v < PT_MIN_T) && v <= closest) {  // (the first candidate of a fresh walk: closest is still MAX_T, nothing to tie with)
+          closest = v;
+          hit_pos = base;
+        }
+      }
+    }
+  } else
+#endif
   {
     const uint32_t n_grp = (A.n_outliers + 3u) >> 2;
     for (uint32_t gi = 0; gi < n_grp; gi++) {

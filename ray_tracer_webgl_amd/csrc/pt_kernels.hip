@@ -50,12 +50,6 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(
   pt_trace_body<false, false>(A);
 }
 
-// lists of at most 16 spheres (PT_GEOM_SMALL: the reference's own scene size): no LDS in the scan, no candidate
-// queue, the list reaches the VALU group by group from SGPRs
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small(const PtKernelArgs A) {
-  pt_trace_body<false, true, 7>(A);
-}
-
 // The walk kernels are latency-bound, not issue-bound: for scenes small enough that LDS
 // leaves room for them, six waves per SIMD (80 VGPRs) beat five with no spills (config 2: -5 %).
 // The kernels for larger scenes are held to four waves by their LDS footprint and keep their

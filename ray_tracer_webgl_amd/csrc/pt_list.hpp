@@ -207,35 +207,72 @@ __device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p,
   // the candidate test as ONE bit of sign arithmetic (pt_grid_walk.hpp: `ds + 0` has a clear sign bit iff
   // !(ds < 0); a set sign bit in c or half_b means "not provably behind"; regular rays only)
   auto pass_bit = [](float hb, float cc, float ds) -> uint32_t { return ((f2u(cc) | f2u(hb)) & ~f2u(ds + 0.0f)) >> 31; };
-#pragma unroll
-  for (uint32_t g = 0; g < 4u; g++) {
-    const uint32_t base = 4u * g;
-    if (base < n_spheres) { // wave-uniform
-      const f4v e0 = c_geom[base], e1 = c_geom[base + 1u], e2 = c_geom[base + 2u], e3 = c_geom[base + 3u];
-      float hb0, cc0, ds0; sphere_test(o, d, a, e0, hb0, cc0, ds0);
-      float hb1, cc1, ds1; sphere_test(o, d, a, e1, hb1, cc1, ds1);
-      float hb2, cc2, ds2; sphere_test(o, d, a, e2, hb2, cc2, ds2);
-      float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
-      uint32_t mask = 0u;
-      if (scan_lane) {
-        mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
-        const uint32_t left = n_spheres - base; // >= 1, wave-uniform
-        mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
-      }
-      for (;;) {
-        if (pt_ballot(mask != 0u) == 0ull) break;
-        if (mask != 0u) {
-          const uint32_t k = first_candidate(mask); // ascending list order
-          mask &= mask - 1u;
-          const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
-          const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));
-          const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161
-          if (!(v < PT_MIN_T) && v <= closest) { // :159-161, sequentially: a later sphere at the same root wins
-            closest = v;
-            hit = (int)(base + k);
-          }
+  // the candidates of one group (mask: one bit per sphere of the group), finished in lockstep from the values still in
+  // registers, in ascending list order
+  auto finish = [&](uint32_t base, uint32_t mask, float hb0, float hb1, float hb2, float hb3, float ds0, float ds1, float ds2, float ds3) {
+    for (;;) {
+      if (pt_ballot(mask != 0u) == 0ull) break;
+      if (mask != 0u) {
+        const uint32_t k = first_candidate(mask); // ascending list order
+        mask &= mask - 1u;
+        const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
+        const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));
+        const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161
+        if (!(v < PT_MIN_T) && v <= closest) { // :159-161, sequentially: a later sphere at the same root wins
+          closest = v;
+          hit = (int)(base + k);
         }
       }
+    }
+  };
+  if constexpr (S::SMALL_TAIL < 0) {
+    // any list length: every group tests four entries (the last one's padding is masked)
+#pragma unroll
+    for (uint32_t g = 0; g < 4u; g++) {
+      const uint32_t base = 4u * g;
+      if (base < n_spheres) { // wave-uniform
+        const f4v e0 = c_geom[base], e1 = c_geom[base + 1u], e2 = c_geom[base + 2u], e3 = c_geom[base + 3u];
+        float hb0, cc0, ds0; sphere_test(o, d, a, e0, hb0, cc0, ds0);
+        float hb1, cc1, ds1; sphere_test(o, d, a, e1, hb1, cc1, ds1);
+        float hb2, cc2, ds2; sphere_test(o, d, a, e2, hb2, cc2, ds2);
+        float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
+        uint32_t mask = 0u;
+        if (scan_lane) {
+          mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
+          const uint32_t left = n_spheres - base; // >= 1, wave-uniform
+          mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
+        }
+        finish(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
+      }
+    }
+  } else {
+    // a list of 4 q + SMALL_TAIL spheres (the build for this remainder): q full groups, nothing to mask, then a
+    // last group of exactly SMALL_TAIL tests — the padding entries of a nine-sphere list (the reference's
+    // State::default, config 4) cost three tests per segment otherwise
+    const uint32_t n_full = n_spheres >> 2;  // wave-uniform
+#pragma unroll
+    for (uint32_t g = 0; g < 4u; g++) {
+      if (g < n_full) { // wave-uniform
+        const uint32_t base = 4u * g;
+        const f4v e0 = c_geom[base], e1 = c_geom[base + 1u], e2 = c_geom[base + 2u], e3 = c_geom[base + 3u];
+        float hb0, cc0, ds0; sphere_test(o, d, a, e0, hb0, cc0, ds0);
+        float hb1, cc1, ds1; sphere_test(o, d, a, e1, hb1, cc1, ds1);
+        float hb2, cc2, ds2; sphere_test(o, d, a, e2, hb2, cc2, ds2);
+        float hb3, cc3, ds3; sphere_test(o, d, a, e3, hb3, cc3, ds3);
+        uint32_t mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
+        mask = scan_lane ? mask : 0u;
+        finish(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
+      }
+    }
+    if constexpr (S::SMALL_TAIL > 0) {
+      const uint32_t base = 4u * n_full;
+      float hb0 = 0.f, cc0 = 0.f, ds0 = -1.f, hb1 = 0.f, cc1 = 0.f, ds1 = -1.f, hb2 = 0.f, cc2 = 0.f, ds2 = -1.f;
+      { const f4v e0 = c_geom[base]; sphere_test(o, d, a, e0, hb0, cc0, ds0); }
+      uint32_t mask = pass_bit(hb0, cc0, ds0);
+      if constexpr (S::SMALL_TAIL > 1) { const f4v e1 = c_geom[base + 1u]; sphere_test(o, d, a, e1, hb1, cc1, ds1); mask |= pass_bit(hb1, cc1, ds1) << 1; }
+      if constexpr (S::SMALL_TAIL > 2) { const f4v e2 = c_geom[base + 2u]; sphere_test(o, d, a, e2, hb2, cc2, ds2); mask |= pass_bit(hb2, cc2, ds2) << 2; }
+      mask = scan_lane ? mask : 0u;
+      finish(base, mask, hb0, hb1, hb2, hb2, ds0, ds1, ds2, ds2);
     }
   }
   h.closest = closest; h.hit = hit;

@@ -109,13 +109,17 @@ struct GridWalk {  // boundary-crossing times, linear cell index, steps left per
 //                7     no structure, the LDS copy only for per-lane gathers: a list of at most 16 spheres (the reference's
 //                      u_sphere_list[15], static/shader.frag:103) tested group by group from SGPRs.
 //              List-order reads (tail mode, PHASE 3, shading) go to the global copy.
-template <bool SCAN_LDS_, bool HAVE_LDS_, int WALK_>
+template <bool SCAN_LDS_, bool HAVE_LDS_, int WALK_, int TAIL_ = -1>
 struct Scene {
   static constexpr bool SCAN_LDS = SCAN_LDS_, HAVE_LDS = HAVE_LDS_;
   static constexpr int WALK = WALK_;
   static constexpr bool BVH = WALK >= 1 && WALK <= 3;
   static constexpr bool GRID = WALK >= 4 && WALK <= 6;
   static constexpr bool SMALL = WALK == 7;   // at most 16 spheres, tested straight from SGPRs (pt_list.hpp small_scan)
+  // small-list builds: the list holds 4 q + SMALL_TAIL spheres (0 .. 3: the build for that remainder, pt_kernels_small.hip);
+  // -1: any length, the last group's padding tested and masked (the opt-in builds of pt_kernels_extra.hip)
+  static constexpr int SMALL_TAIL = TAIL_;
+  static_assert(TAIL_ >= -1 && TAIL_ <= 3 && (TAIL_ < 0 || WALK_ == 7), "a list remainder belongs to the small-list kernel");
   static constexpr bool TREE = BVH || GRID;  // a culling structure: hits are (slot, value) pairs
   static constexpr int BVH_MODE = BVH ? WALK : 0;
   static constexpr bool NODES_LDS = WALK == 1 || WALK == 2;

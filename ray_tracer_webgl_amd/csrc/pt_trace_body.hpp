@@ -19,12 +19,12 @@ using namespace ptd;
 // --------------------------------------------------------------------------------------------
 // The path-tracing kernel body: one persistent wave working through (pixel, pass) items.
 // Template parameters: pt_scene.hpp `Scene`; COUNT = the measuring twin (tallies live); RR = the
-// opt-in Russian-roulette build (pt_shade.hpp).
+// opt-in Russian-roulette build (pt_shade.hpp); TAIL = the small-list builds' list remainder (pt_scene.hpp SMALL_TAIL).
 // --------------------------------------------------------------------------------------------
-template <bool SCAN_LDS, bool HAVE_LDS, int WALK = 0, bool COUNT = false, bool RR = false>
+template <bool SCAN_LDS, bool HAVE_LDS, int WALK = 0, bool COUNT = false, bool RR = false, int TAIL = -1>
 __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   using namespace ptk;
-  using S = Scene<SCAN_LDS, HAVE_LDS, WALK>;
+  using S = Scene<SCAN_LDS, HAVE_LDS, WALK, TAIL>;
   S::stage(A);
 
   Path p;           // per lane

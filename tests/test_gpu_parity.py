@@ -1194,6 +1194,36 @@ def test_measuring_twin_equals_the_timed_kernel(ora, path):
     t.close()
 
 
+def test_small_list_twin_and_remainder_builds_agree(ora):
+    """The small-list kernel exists once per list length modulo four (pt_kernels_small.hip: the last group
+    tests exactly its own spheres) and once for any length (the measuring twin and the roulette build of
+    pt_kernels_extra.hip: padding tested and masked).  Same bits and segment counts from both, on lists of
+    every remainder, and the twin's phase clock runs (tools/wave_log.py reads it for config 4)."""
+    import ctypes as C
+    from test_gpu_fuzz import random_scene
+
+    for seed, n in enumerate([9, 10, 11, 12, 1, 6]):
+        rng = np.random.default_rng(47000 + seed)
+        sc = random_scene(rng, n, 96, 54, 2, 8, 2)
+        t, got = render_scene(sc, geometry_path=abi.PT_GEOM_SMALL)
+        st = t.stats()
+        assert st.geometry_path == abi.PT_GEOM_SMALL
+        t.reset()
+        t.set_count_work(True)
+        t.set_params(sc.params)
+        t.render_passes(2)
+        assert_bit_equal(t.accum(), got, "small-list twin vs the build for %d spheres" % n)
+        assert t.stats().segments == st.segments
+        ctr = np.zeros(128, np.uint64)
+        t.lib.pt_debug_counters.restype = C.c_long
+        t.lib.pt_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        assert t.lib.pt_debug_counters(t._ctx, ctr.ctypes.data_as(C.c_void_p), 128) == 128
+        assert ctr[24:32].sum() > 0 and ctr[24 + 7] > 0  # the phase clock ran; shading took some of it
+        ref, seg = ora.render(sc.spheres, sc.params, 2)
+        assert_bit_equal(got, ref, "small list of %d spheres vs oracle" % n)
+        t.close()
+
+
 @pytest.mark.parametrize("path", [abi.PT_GEOM_BVH, abi.PT_GEOM_GRID])
 def test_carrying_stragglers_is_scheduling_only(ora, path):
     """PT_OPT_CARRY_LANES decides when a wave stops waiting for its last walks (they continue in

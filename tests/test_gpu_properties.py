@@ -258,7 +258,7 @@ def test_bench_single_gpu_line_matches_the_committed_digest():
     assert d["roofline"]["frac"] and 0 < d["roofline"]["frac"] <= 1
 
 
-@pytest.mark.parametrize("config,kernels", [("4", ("pt_trace_kernel_small", "pt_trace_kernel", "pt_trace_kernel_scalar")),
+@pytest.mark.parametrize("config,kernels", [("4", ("pt_trace_kernel_small_t1", "pt_trace_kernel", "pt_trace_kernel_scalar")),
                                             ("5", ("pt_trace_kernel_grid_cells", "pt_trace_kernel_bvh_nodes"))])
 def test_bench_lines_of_the_stress_configs(config, kernels):
     """`bench.py --config 4 / 5`: BASELINE's closed room and 10 000-sphere field through the same line
