@@ -934,11 +934,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     const size_t lds_room = walk_lds_room();
     const size_t scene = path == PT_GEOM_BVH ? bind_hierarchy(c, rr, lds_room, A, &kfn) : bind_grid(c, rr, lds_room, A, &kfn);
     A.lds_scene_bytes = (uint32_t)scene;
-    // tail mode costs ~n/64 rounds per live ray, the walk a roughly constant ~1500 issue slots
-    // per wave: the turn-around only pays for the last few rays of a wave
-    const uint32_t per_ray = c->n_spheres / 64u * 45u + 70u;
-    const uint32_t lim = 1500u / per_ray;
-    A.coop_max_live = lim > 16u ? 16u : lim;
+    A.coop_max_live = 0;  // (the walk kernels have no tail mode: pt_trace_body.hpp)
     block = walk_block_threads(kfn, scene, lds_max);
     lds = scene + (size_t)PT_PARK_STRIDE * 4 * block;
   } else {

@@ -78,8 +78,10 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
 
   // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is
   // padded with entries that never pass); carried lanes have done this
-#ifdef PT_ALWAYS_ONE  // dev A/B: a scene with ONE always-tested sphere (a ground: config 5) tests it alone, not beside three padding entries
-  if (A.n_outliers == 1u) {
+  // A scene with ONE always-tested sphere (a ground under a field: config 5) tests it alone, not beside three padding
+  // entries: -2 % there.  Only in the builds whose entries are not staged in the LDS (large scenes): in
+  // pt_trace_kernel_grid the wave-uniform branch alone cost config 2 +0.8 % (four always-tested spheres: a full group).
+  if (S::WALK != 4 && A.n_outliers == 1u) {
     const uint32_t base = n_cell_entries;
     float4 e0;
     if constexpr (S::WALK == 4) { e0 = S::slot_at(A, base); }
@@ -96,9 +98,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
         }
       }
     }
-  } else
-#endif
-  {
+  } else {
     const uint32_t n_grp = (A.n_outliers + 3u) >> 2;
     for (uint32_t gi = 0; gi < n_grp; gi++) {
       const uint32_t base = n_cell_entries + 4u * gi;
