@@ -215,40 +215,20 @@ __device__ __forceinline__ lds_u32* park_of(const PtKernelArgs& A) {
 }
 __device__ __forceinline__ void park_store(const PtKernelArgs& A, const Path& p) {
   lds_u32* ps = park_of(A);
-#if !defined(PT_UNPARK) || PT_UNPARK < 6
   ps[0] = f2u(p.sum.x); ps[1] = f2u(p.sum.y); ps[2] = f2u(p.sum.z);
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 3
   ps[3] = f2u(p.col.x); ps[4] = f2u(p.col.y); ps[5] = f2u(p.col.z);
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 7
   ps[6] = f2u(p.seed);
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 9
   ps[7] = f2u(p.st_s); ps[8] = f2u(p.st_t);
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 11
   ps[12] = (uint32_t)p.sample; ps[13] = (uint32_t)p.depth;
-#endif
   ps[9] = p.slab_index; ps[10] = p.item_tile; ps[11] = p.item_segs;
 }
 __device__ __forceinline__ void park_load(const PtKernelArgs& A, Path& p) {
   lds_u32* ps = park_of(A);
-#if !defined(PT_UNPARK) || PT_UNPARK < 6
   p.sum = mk(u2f(ps[0]), u2f(ps[1]), u2f(ps[2]));
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 3
   p.col = mk(u2f(ps[3]), u2f(ps[4]), u2f(ps[5]));
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 7
   p.seed = u2f(ps[6]);
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 9
   p.st_s = u2f(ps[7]); p.st_t = u2f(ps[8]);
-#endif
-#if !defined(PT_UNPARK) || PT_UNPARK < 11
   p.sample = (int)ps[12]; p.depth = (int)ps[13];
-#endif
   p.slab_index = ps[9]; p.item_tile = ps[10]; p.item_segs = ps[11];
 }
 
