@@ -946,6 +946,17 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
           : path == PT_GEOM_LDS ? PT_KFN(pt_trace_kernel)
                                 : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar, PT_X_SCALAR_RR)
                                             : PT_PICK(rr, pt_trace_kernel_scalar_nolds, PT_X_SCALAR_NOLDS_RR));
+    // tail mode (list kernels only): a turn-around costs ~(n / 64 + 1) x 60 + 60 issue slots per live ray, a step of the
+    // scan ~12 n + 700 for the wave: it pays while the live rays are fewer than the ratio (484 spheres: 12 — measured
+    // 155.7 / 17.21 ms per 16-pass / 1-pass launch against 157.5 / 17.46 at 16 and 158.2 / 18.10 without it)
+    {
+      const uint32_t per_ray = (c->n_spheres / 64u + 1u) * 60u + 60u;
+      const uint32_t lim = (12u * c->n_spheres + 700u) / per_ray;
+      A.coop_max_live = lim > 16u ? 16u : lim;
+#ifdef PT_DEV_KNOBS
+      if (const char* e = getenv("PT_COOP_MAX")) A.coop_max_live = (uint32_t)atoi(e);
+#endif
+    }
     // 256-thread workgroups while several fit per CU; one 1024-thread workgroup per CU when the list
     // takes most of the 160 KiB LDS
     block = lds > 40 * 1024 ? 1024u : 256u;

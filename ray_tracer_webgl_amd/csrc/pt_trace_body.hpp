@@ -62,8 +62,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // by all 64 lanes.  The walk kernels do not have it: a walk costs a wave ~1 500 issue slots whatever its lane count
     // and a turn-around n / 64 x 45 + 70 per ray, so it only ever served waves of <= 3 live rays there (config 2), while
     // its test (three ballots per step) and its code cost every step: without it config 2 -1.3 %, the hierarchy -1 %, one
-    // rank's band of eight -0.9 ... -1.4 % (profiles/r04_ab_runs.txt).
-    const bool coop = !S::TREE && (n_live <= (int)A.coop_max_live) && (pt_ballot(p.alive && !fast) == 0ull) &&
+    // rank's band of eight -0.9 ... -1.4 % (profiles/r04_ab_runs.txt).  Nor do the small-list kernels: a turn-around per ray
+    // costs what a whole step over nine spheres costs — without it config 4 -2 %, the reference's 1-spp frame 0.132 -> 0.114 ms.
+    constexpr bool kTail = !S::TREE && !S::SMALL;
+    const bool coop = kTail && (n_live <= (int)A.coop_max_live) && (pt_ballot(p.alive && !fast) == 0ull) &&
                       (pt_ballot(cw.carried) == 0ull);
     if (coop) {
       tail_mode<S>(A, p, live, h);

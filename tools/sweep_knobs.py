@@ -14,7 +14,7 @@ def child():
         sc = scenes.config2(1920, 1080, spp, n, 50)
     sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
     pt = PathTracer(1920, 1080)
-    pt.set_geometry_path(abi.PT_GEOM_GRID)
+    pt.set_geometry_path(int(os.environ.get("SW_PATH", abi.PT_GEOM_GRID)))
     if os.environ.get("SW_CARRY"): pt.set_carry_lanes(int(os.environ["SW_CARRY"]))
     if os.environ.get("SW_REFILL"): pt.set_refill_min(int(os.environ["SW_REFILL"]))
     pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(n)
