@@ -78,6 +78,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
 
   // the always-tested spheres, four at a time (wave-uniform scalar loads; the last group is
   // padded with entries that never pass); carried lanes have done this
+  tally.always_group(true);
   // A scene with ONE always-tested sphere (a ground under a field: config 5) tests it alone, not beside three padding
   // entries: -2 % there.  Only in the builds whose entries are not staged in the LDS (large scenes): in
   // pt_trace_kernel_grid the wave-uniform branch alone cost config 2 +0.8 % (four always-tested spheres: a full group).
@@ -121,6 +122,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     }
   }
 
+  tally.always_group(false);
   tally.phase(2);
   // per-ray constants of the walk (recomputed for carried lanes: cheaper than keeping them)
   const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f);

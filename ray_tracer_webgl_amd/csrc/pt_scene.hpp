@@ -241,6 +241,8 @@ struct Tally {
   uint32_t tb_bin = 0xffffffffu, tb_acc = 0;
   uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
            n_carried = 0;
+  uint32_t n_exact_always_it = 0, n_exact_always_ln = 0;  // (the share of the exact evaluations that serves the always-tested group)
+  bool in_always = false;
   // phase clock (shader cycles, s_memtime): where a wave's time goes
   //   0 refill  1 camera ray  2 always-tested spheres (hierarchy: set-up + outliers)  3 per-ray constants + grid entry
   //   4 advance / node loops  5 leaf + exact  6 literal + parking + the rest  7 shade
@@ -254,7 +256,13 @@ struct Tally {
   }
   __device__ __forceinline__ void walk(unsigned long long mask) { if constexpr (COUNT) { n_walk_it++; n_walk_ln += (uint32_t)__popcll(mask); } }
   __device__ __forceinline__ void leaf(unsigned long long mask) { if constexpr (COUNT) { n_leaf_it++; n_leaf_ln += (uint32_t)__popcll(mask); } }
-  __device__ __forceinline__ void exact(unsigned long long mask) { if constexpr (COUNT) { n_exact_it++; n_exact_ln += (uint32_t)__popcll(mask); } }
+  __device__ __forceinline__ void exact(unsigned long long mask) {
+    if constexpr (COUNT) {
+      n_exact_it++; n_exact_ln += (uint32_t)__popcll(mask);
+      if (in_always) { n_exact_always_it++; n_exact_always_ln += (uint32_t)__popcll(mask); }
+    }
+  }
+  __device__ __forceinline__ void always_group(bool on) { if constexpr (COUNT) in_always = on; }
   __device__ __forceinline__ void step() { if constexpr (COUNT) n_steps++; }
   __device__ __forceinline__ void carried(bool c) { if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(c)); }
   // who takes PHASE 3 (the literal loop over the whole list): irregular rays, and regular ones the walk hands over
@@ -300,6 +308,8 @@ struct Tally {
         atomicAdd(&A.counters[PT_CTR_WORK + 5], (unsigned long long)n_exact_ln);
         atomicAdd(&A.counters[PT_CTR_WORK + 6], (unsigned long long)n_steps);
         atomicAdd(&A.counters[PT_CTR_WORK + 7], (unsigned long long)n_carried);
+        atomicAdd(&A.counters[PT_CTR_LITERAL + 5], (unsigned long long)n_exact_always_it);
+        atomicAdd(&A.counters[PT_CTR_LITERAL + 6], (unsigned long long)n_exact_always_ln);
         if (tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
         for (int k = 0; k < PT_N_PHASES; k++) atomicAdd(&A.counters[PT_CTR_PHASES + k], ph_t[k]);
         if (A.wave_log) {

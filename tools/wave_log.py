@@ -68,6 +68,11 @@ print("   " + " ".join("%.1f" % (bins[b] / 0.65536e-3 / 1e9) for b in order if b
 ph = ctr[24:32].astype(np.float64)
 names = ["refill", "camera ray", "park + always-tested", "per-ray constants + entry", "advance / node loops", "leaf + exact", "literal + unpark", "shade"]
 print("  wave-time shares by phase (s_memtime): " + ", ".join("%s %.3f" % (n_, v / ph.sum()) for n_, v in zip(names, ph)))
+w = ctr[8:16].astype(np.float64)
+per = 64.0 / max(float(st.segments), 1.0)
+print("  per 64 segments: %.2f advance trips x %.1f lanes, %.2f leaf rounds x %.1f, %.2f exact evaluations x %.1f (of them for the always-tested "
+      "group: %.2f x %.1f), %.3f wave steps" % (w[0] * per, w[1] / max(w[0], 1), w[2] * per, w[3] / max(w[2], 1), w[4] * per, w[5] / max(w[4], 1),
+                                                 float(ctr[21]) * per, float(ctr[22]) / max(float(ctr[21]), 1.0), w[6] * per))
 lit = ctr[16:21]
 print("  PHASE 3 (literal loop): %d irregular lane-steps, %d handed over by the walk, %d wave steps; last irregular pixel (slab index) %d, last handed-over %d"
       % (lit[0], lit[1], lit[2], int(lit[3]) - 1, int(lit[4]) - 1))
