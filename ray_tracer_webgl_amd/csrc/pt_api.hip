@@ -942,7 +942,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     // SCAN reads (their per-lane gathers — shading, tail mode — still come from the copy)
     const bool have_lds = c->n_spheres <= PT_MAX_SPHERES_LDS;
     lds = have_lds ? (size_t)PT_LDS_ENTRIES(c->n_spheres) * 16 : 0;
-    kfn = path == PT_GEOM_SMALL ? (c->count_work ? extra_kernel(c->device, PT_X_SMALL_COUNT) : (rr ? extra_kernel(c->device, PT_X_SMALL_RR) : pt_small_kernel(c->n_spheres)))
+    kfn = path == PT_GEOM_SMALL ? (c->count_work ? extra_kernel(c->device, PT_X_SMALL_COUNT) : (rr ? extra_kernel(c->device, PT_X_SMALL_RR + (int)(c->n_spheres & 3u)) : pt_small_kernel(c->n_spheres)))
           : path == PT_GEOM_LDS ? PT_KFN(pt_trace_kernel)
                                 : (have_lds ? PT_PICK(rr, pt_trace_kernel_scalar, PT_X_SCALAR_RR)
                                             : PT_PICK(rr, pt_trace_kernel_scalar_nolds, PT_X_SCALAR_NOLDS_RR));

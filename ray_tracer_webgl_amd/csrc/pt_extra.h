@@ -2,7 +2,7 @@
 #pragma once
 enum {
   PT_X_BVH_COUNT = 0, PT_X_GRID_COUNT, PT_X_GRID_CELLS_COUNT, PT_X_SMALL_COUNT,
-  PT_X_SMALL_RR, PT_X_SCALAR_RR, PT_X_SCALAR_NOLDS_RR, PT_X_BVH_RR, PT_X_BVH_NODES_RR, PT_X_BVH_GMEM_RR,
+  PT_X_SMALL_RR /* + list length % 4: four builds */, PT_X_SCALAR_RR = PT_X_SMALL_RR + 4, PT_X_SCALAR_NOLDS_RR, PT_X_BVH_RR, PT_X_BVH_NODES_RR, PT_X_BVH_GMEM_RR,
   PT_X_GRID_RR, PT_X_GRID_CELLS_RR, PT_X_GRID_GMEM_RR, PT_X_COUNT
 };
 // the kernel's host-side handle (what hipLaunchKernel takes); asking for it loads nothing yet

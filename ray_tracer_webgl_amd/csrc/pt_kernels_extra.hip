@@ -2,7 +2,7 @@
 // code object) of their own: the Russian-roulette kernels (PT_OPT_RUSSIAN_ROULETTE, pt_shade.hpp) and the
 // measuring twins (PT_OPT_COUNT_WORK: the same bodies with the executed-work tallies and the phase clock
 // live).  The HIP runtime loads a code object when one of its kernels is first asked for, so a context that
-// never turns these options on never pays for the thirteen kernels in here (round 3: one 557 KB code object
+// never turns these options on never pays for the sixteen kernels in here (round 3: one 557 KB code object
 // with 22 instantiations of the body, loaded by every context's first launch).  pt_api.hip reaches them
 // through pt_extra_kernel() only.
 #include "pt_trace_body.hpp"
@@ -24,8 +24,18 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_count(c
 }
 
 // Russian-roulette builds (PT_OPT_RUSSIAN_ROULETTE, opt-in; same launch shapes as their namesakes)
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_rr(const PtKernelArgs A) {
-  pt_trace_body<false, true, 7, false, true>(A);
+// (the small-list kernel: one build per list length modulo four, like pt_kernels_small.hip)
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t0_rr(const PtKernelArgs A) {
+  pt_trace_body<false, true, 7, false, true, 0>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t1_rr(const PtKernelArgs A) {
+  pt_trace_body<false, true, 7, false, true, 1>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t2_rr(const PtKernelArgs A) {
+  pt_trace_body<false, true, 7, false, true, 2>(A);
+}
+extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t3_rr(const PtKernelArgs A) {
+  pt_trace_body<false, true, 7, false, true, 3>(A);
 }
 extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 0, false, true>(A);
@@ -59,7 +69,10 @@ extern "C" const void* pt_extra_kernel(int id) {
     case PT_X_GRID_COUNT: return reinterpret_cast<const void*>(pt_trace_kernel_grid_count);
     case PT_X_GRID_CELLS_COUNT: return reinterpret_cast<const void*>(pt_trace_kernel_grid_cells_count);
     case PT_X_SMALL_COUNT: return reinterpret_cast<const void*>(pt_trace_kernel_small_count);
-    case PT_X_SMALL_RR: return reinterpret_cast<const void*>(pt_trace_kernel_small_rr);
+    case PT_X_SMALL_RR + 0: return reinterpret_cast<const void*>(pt_trace_kernel_small_t0_rr);
+    case PT_X_SMALL_RR + 1: return reinterpret_cast<const void*>(pt_trace_kernel_small_t1_rr);
+    case PT_X_SMALL_RR + 2: return reinterpret_cast<const void*>(pt_trace_kernel_small_t2_rr);
+    case PT_X_SMALL_RR + 3: return reinterpret_cast<const void*>(pt_trace_kernel_small_t3_rr);
     case PT_X_SCALAR_RR: return reinterpret_cast<const void*>(pt_trace_kernel_scalar_rr);
     case PT_X_SCALAR_NOLDS_RR: return reinterpret_cast<const void*>(pt_trace_kernel_scalar_nolds_rr);
     case PT_X_BVH_RR: return reinterpret_cast<const void*>(pt_trace_kernel_bvh_rr);

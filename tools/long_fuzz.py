@@ -1,4 +1,7 @@
-"""Dev tool: many more seeds of tests/test_gpu_fuzz.py's generator than the suite runs."""
+"""Dev tool: many more seeds of tests/test_gpu_fuzz.py's generator than the suite runs.
+
+    python tools/long_fuzz.py <first seed> <last seed> [bvh | grid | small]     (no third argument: a random path per scene)
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -10,17 +13,22 @@ from test_gpu_fuzz import random_scene
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bvh = len(sys.argv) > 3 and sys.argv[3] in ("bvh", "grid")  # force a walk kernel on scenes that get a structure
 grid = len(sys.argv) > 3 and sys.argv[3] == "grid"
+force_small = len(sys.argv) > 3 and sys.argv[3] == "small"  # force the small-list kernels on lists of 1 .. 16 spheres
 used = 0
 bad = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500, 4000] if bvh else [1, 2, 5, 9, 17, 40, 130, 400]))
+    if force_small:  # every list length the small-list kernels exist for (one build per length modulo four)
+        n = int(rng.integers(1, 17))
     width, height = int(rng.integers(9, 200)), int(rng.integers(5, 120))
     if n >= 400:
         width, height = min(width, 64), min(height, 40)
     spp, depth, passes = int(rng.integers(1, 9)), int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 5))
     sc = random_scene(rng, n, width, height, spp, depth, passes)
     path = int(rng.choice([0, 1, 2, 3, 4, 5, 5]))  # auto, LDS, scalar, hierarchy, grid, small (falls back beyond 16 spheres)
+    if force_small:
+        path = 5
     if bvh:
         path = 4 if grid else 3
         if grid and seed % 2 == 0:  # mostly small spheres: what a grid is for (the rest: wild radii, many always-tested)
