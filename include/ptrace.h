@@ -289,8 +289,10 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
  * texture[(even_odd_count + 1) % 2] by the shader's render() rule using params.render_count /
  * should_average / last_frame_weight, draw the result to the canvas and, when should_average, to
  * texture[even_odd_count % 2].  Asynchronous on the context's stream; nothing crosses PCIe.
- * pt_render_frames replays n_frames ticks at a constant frame interval from ONE captured hipGraph
- * (trace + blend + advance; re-captured only when uniforms or scene changed), with the per-frame
+ * pt_render_frames replays n_frames ticks at a constant frame interval from captured hipGraphs —
+ * groups of eight frames (ONE trace launch renders the group's frames as its passes into slabs of
+ * their own, allocated by the first call that needs them; their blends follow in order; advance) and
+ * single frames for the remainder (trace + blend + advance) — with the per-frame
  * state of State::update_render_globals (src/state.rs:443-450) kept on the device: frame k of the
  * call renders at u_time = time + float(first_pass + k) * time_step with
  * render_count = min(params.render_count + k, max_render_count) and even_odd_count + k — the bits

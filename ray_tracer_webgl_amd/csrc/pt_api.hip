@@ -108,7 +108,11 @@ struct pt_ctx {
   uint32_t* d_canvas = nullptr;
   size_t tex_pixels = 0;
   uint32_t* d_frame_ctr = nullptr;
-  hipGraphExec_t frame_exec = nullptr;   // one frame (trace + blend + advance), captured once per uniform set
+  hipGraphExec_t frame_exec = nullptr;   // one frame (trace + blend + advance), captured once per plan (FramePlan below)
+  hipGraphExec_t frames_exec = nullptr;  // kFramesPerGraph frames: ONE trace launch of that many passes, their blends in order, advance
+  unsigned char frames_plan[1024] = {0};
+  float4* d_frame_slab = nullptr;        // the group's slabs (kFramesPerGraph passes), allocated by the first pt_render_frames that needs them
+  size_t frame_slab_pixels = 0;
   uint64_t epoch = 0;                    // bumped by everything a captured frame bakes in
   unsigned char frame_plan[1024] = {0};  // the FramePlan the cached graph was captured from (compared bytewise)
   // counters + timing
@@ -143,6 +147,13 @@ int fail(pt_ctx* c, int code, const char* fmt, ...) {
       return fail((c), PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
                   __FILE__, __LINE__);                                                      \
   } while (0)
+
+// frames per replayed graph (pt_render_frames; measured on the reference's 1280x702 1-spp frame: 1 / 2 / 4 / 8 / 16 / 32 frames
+// per graph -> 8 190 / 12 690 / 18 960 / 21 040 / 21 790 / 21 000 frames per second)
+#ifndef PT_FRAMES_PER_GRAPH
+#define PT_FRAMES_PER_GRAPH 8
+#endif
+constexpr uint32_t kFramesPerGraph = PT_FRAMES_PER_GRAPH;  // (dev A/B builds override it)
 
 uint32_t count_local_rows(uint32_t height, const PtParams& p) {
   return pt_local_rows(height, p.band_rows, p.band_index, p.band_count);
@@ -381,6 +392,8 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_resolve) (void)hipFree(c->d_resolve);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->frame_exec) (void)hipGraphExecDestroy(c->frame_exec);
+  if (c->frames_exec) (void)hipGraphExecDestroy(c->frames_exec);
+  if (c->d_frame_slab) (void)hipFree(c->d_frame_slab);
   if (c->d_frame_ctr) (void)hipFree(c->d_frame_ctr);
   for (int k = 0; k < 2; k++) if (c->d_tex[k]) (void)hipFree(c->d_tex[k]);
   if (c->d_canvas) (void)hipFree(c->d_canvas);
@@ -911,7 +924,7 @@ static uint32_t walk_block_threads(const void* kfn, size_t scene, size_t lds_max
   return block ? block : 1024u;
 }
 
-static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L) {
+static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L, bool deal_statically = false) {
   PtKernelArgs& A = L->A;
   {
     int rc = fill_uniforms(c, n_passes, A);
@@ -992,7 +1005,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   // items round-robin to the waves instead (no atomic; the cost-ordered tile list still spreads the
   // heavy tiles over the waves).
   A.n_waves = grid * (block / 64u);
-  A.queue_static = items < 8ull * (unsigned long long)A.n_waves * 64ull ? 1u : 0u;
+  A.queue_static = (deal_statically || items < 8ull * (unsigned long long)A.n_waves * 64ull) ? 1u : 0u;
   if (A.queue_static) A.queue_chunk = 64u;
 
   L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;
@@ -1125,12 +1138,17 @@ struct FramePlan {
   hipStream_t stream = nullptr;
   float4* slab = nullptr;
   uint32_t* tex0 = nullptr; uint32_t* tex1 = nullptr; uint32_t* canvas = nullptr;
+  uint32_t n_frames = 1;  // frames traced by the one launch (as its passes), blended one after the other
 };
 static_assert(sizeof(FramePlan) <= sizeof(pt_ctx::frame_plan), "pt_ctx::frame_plan must hold a FramePlan");
 
-int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_render_count, FramePlan* F) {
+int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_render_count, uint32_t n_frames, float4* slab, FramePlan* F) {
   memset(static_cast<void*>(F), 0, sizeof *F);  // (padding too: plans are compared bytewise)
-  int rc = prepare_launch(c, 1, false, &F->L);
+  // frames k .. k + n - 1 are the passes 0 .. n - 1 of ONE launch: pass p renders at u_time = time + float(first_pass + p + k) *
+  // time_step (pt_refill.hpp), which IS frame k + p's time, into slab p
+  // (a group of frames is still a short launch of uniform items: dealt statically whatever its size, since the shared
+  // queue's atomics would cost more than the frames — 8 frames of the reference's size: 0.37 ms per frame with them)
+  int rc = prepare_launch(c, n_frames, false, &F->L, true);
   if (rc != PT_OK) return rc;
   F->L.A.frame_ctr = ctr;
   F->L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
@@ -1138,25 +1156,30 @@ int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_rende
   F->ctr = ctr; F->even_odd0 = even_odd0; F->max_render_count = max_render_count;
   F->render_count0 = c->params.render_count; F->should_average = c->params.should_average;
   F->last_frame_weight = c->params.last_frame_weight;
-  F->stream = c->stream; F->slab = c->d_slab;
+  F->L.A.slab = reinterpret_cast<float*>(slab);
+  F->stream = c->stream; F->slab = slab;
   F->tex0 = c->d_tex[0]; F->tex1 = c->d_tex[1]; F->canvas = c->d_canvas;
+  F->n_frames = n_frames;
   return PT_OK;
 }
 
-// enqueue one planned frame (capture-safe: launches only)
+// enqueue one planned frame — or group of frames — (capture-safe: launches only)
 int enqueue_frame(pt_ctx* c, FramePlan& F, bool advance) {
   {
     void* kargs[] = {&F.L.A};
     PT_HIP(c, hipLaunchKernel(F.L.kfn, dim3(F.L.grid), dim3(F.L.block), kargs, F.L.lds, c->stream));
   }
-  // the frame's one pass sits in the slab ({sum r, g, b, spp} per pixel): blend straight from there
+  // a frame's one pass sits in its slab ({sum r, g, b, spp} per pixel): blend straight from there, frame after frame
+  // (each blend reads the texture the one before it wrote)
   const uint32_t n_pix = c->local_rows * c->width;
-  hipLaunchKernelGGL(pt_frame_blend_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream, c->d_slab, c->d_tex[0],
-                     c->d_tex[1], c->d_canvas, n_pix, F.ctr, F.render_count0, F.even_odd0, F.max_render_count,
-                     F.should_average, F.last_frame_weight);
-  PT_HIP(c, hipGetLastError());
+  for (uint32_t f = 0; f < F.n_frames; f++) {
+    hipLaunchKernelGGL(pt_frame_blend_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream, F.slab + (size_t)f * n_pix,
+                       c->d_tex[0], c->d_tex[1], c->d_canvas, n_pix, F.ctr, f, F.render_count0, F.even_odd0, F.max_render_count,
+                       F.should_average, F.last_frame_weight);
+    PT_HIP(c, hipGetLastError());
+  }
   if (advance) {
-    hipLaunchKernelGGL(pt_frame_advance_kernel, dim3(1), dim3(64), 0, c->stream, c->d_frame_ctr, &c->d_counters[PT_CTR_HEAD]);
+    hipLaunchKernelGGL(pt_frame_advance_kernel, dim3(1), dim3(64), 0, c->stream, c->d_frame_ctr, &c->d_counters[PT_CTR_HEAD], F.n_frames);
     PT_HIP(c, hipGetLastError());
   }
   return PT_OK;
@@ -1198,7 +1221,7 @@ PT_API int pt_render_frame(pt_ctx* c, uint32_t even_odd_count) {
   if (c->local_rows == 0) return PT_OK;
   PT_HIP(c, hipSetDevice(c->device));
   FramePlan F;
-  rc = plan_frame(c, c->d_frame_ctr + 1, even_odd_count, 0x7fffffff, &F);  // frame 0 of a series of one
+  rc = plan_frame(c, c->d_frame_ctr + 1, even_odd_count, 0x7fffffff, 1, c->d_slab, &F);  // frame 0 of a series of one
   if (rc != PT_OK) return rc;
   rc = ensure_tile_order(c);
   if (rc != PT_OK) return rc;
@@ -1226,26 +1249,47 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     return fail(c, PT_ERR_INVALID, "pt_render_frames: the context runs on the legacy default stream (PT_STREAM_LEGACY), which cannot be "
                                    "captured into a hipGraph; give it a stream of its own (pt_set_stream(ctx, NULL) or a created stream) "
                                    "or issue the ticks with pt_render_frame");
-  // everything a frame bakes in, decided outside the capture; the cached graph is reused while that is unchanged
-  // (pt_set_params with the same values, as a frame loop issues before every series, does not re-capture)
-  FramePlan F;
-  rc = plan_frame(c, c->d_frame_ctr, even_odd_count, (int)max_render_count, &F);
-  if (rc != PT_OK) return rc;
+  // Frames in groups of kFramesPerGraph: ONE trace launch renders the group's frames as its passes (each pass has its own
+  // u_time: the frame's), then their blends run in order.  A 1-spp frame of the reference's size is two items per resident
+  // lane, and a wave ends when its slowest lane does: most of a single frame's 0.11 ms is that drain; four frames in one
+  // launch share one.  The remainder of the series is replayed frame by frame.  Same bits either way: a frame is a pass.
+  const uint32_t per_group = n_frames >= kFramesPerGraph ? kFramesPerGraph : 1u;
+  if (per_group > 1u) {  // the group's own slabs (never the slab of pt_render_passes: a caller's captured launches keep theirs)
+    const size_t need = (size_t)c->local_rows * c->width * per_group;
+    if (c->frame_slab_pixels < need) {  // first use at this size: the one allocation this entry point ever makes
+      PT_HIP(c, hipStreamSynchronize(c->stream));
+      if (c->d_frame_slab) PT_HIP(c, hipFree(c->d_frame_slab));
+      c->d_frame_slab = nullptr; c->frame_slab_pixels = 0;
+      PT_HIP(c, hipMalloc(&c->d_frame_slab, need * sizeof(float4)));
+      c->frame_slab_pixels = need;
+    }
+  }
   rc = ensure_tile_order(c);  // outside the capture: it runs once, not per frame
   if (rc != PT_OK) return rc;
-  if (!c->frame_exec || memcmp(&F, &c->frame_plan, sizeof F) != 0) {
-    if (c->frame_exec) { (void)hipGraphExecDestroy(c->frame_exec); c->frame_exec = nullptr; }
+  // everything a graph bakes in is decided outside the capture; a cached graph is reused while that is unchanged
+  // (pt_set_params with the same values, as a frame loop issues before every series, does not re-capture)
+  auto graph_for = [&](uint32_t frames, hipGraphExec_t* exec, unsigned char* plan_store) -> int {
+    FramePlan F;
+    int r = plan_frame(c, c->d_frame_ctr, even_odd_count, (int)max_render_count, frames, frames > 1u ? c->d_frame_slab : c->d_slab, &F);
+    if (r != PT_OK) return r;
+    if (*exec && memcmp(&F, plan_store, sizeof F) == 0) return PT_OK;
+    if (*exec) { (void)hipGraphExecDestroy(*exec); *exec = nullptr; }
     hipGraph_t graph = nullptr;
     PT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    rc = enqueue_frame(c, F, true);
+    r = enqueue_frame(c, F, true);
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc != PT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (r != PT_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
     if (e != hipSuccess) return fail(c, PT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&c->frame_exec, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) { c->frame_exec = nullptr; return fail(c, PT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-    memcpy(static_cast<void*>(&c->frame_plan), &F, sizeof F);
-  }
+    if (e != hipSuccess) { *exec = nullptr; return fail(c, PT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    memcpy(static_cast<void*>(plan_store), &F, sizeof F);
+    return PT_OK;
+  };
+  const uint32_t n_groups = per_group > 1u ? n_frames / per_group : 0u;
+  const uint32_t n_single = n_frames - n_groups * per_group;
+  if (n_groups) { rc = graph_for(per_group, &c->frames_exec, c->frames_plan); if (rc != PT_OK) return rc; }
+  if (n_single) { rc = graph_for(1u, &c->frame_exec, c->frame_plan); if (rc != PT_OK) return rc; }
   // the series starts at frame 0 with an empty queue; every replay leaves both ready for the next
   PT_HIP(c, hipMemsetAsync(c->d_frame_ctr, 0, sizeof(uint32_t), c->stream));
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
@@ -1263,7 +1307,8 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
   }
   std::pair<hipEvent_t, hipEvent_t>& ev = c->events[c->events_used++];
   PT_HIP(c, hipEventRecord(ev.first, c->stream));
-  for (uint32_t k = 0; k < n_frames; k++) PT_HIP(c, hipGraphLaunch(c->frame_exec, c->stream));
+  for (uint32_t g = 0; g < n_groups; g++) PT_HIP(c, hipGraphLaunch(c->frames_exec, c->stream));
+  for (uint32_t k = 0; k < n_single; k++) PT_HIP(c, hipGraphLaunch(c->frame_exec, c->stream));
   PT_HIP(c, hipEventRecord(ev.second, c->stream));
   c->launches += n_frames;
   c->samples += (uint64_t)n_frames * c->local_rows * c->width * (uint64_t)c->params.samples_per_pixel;

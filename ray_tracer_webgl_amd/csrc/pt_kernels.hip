@@ -232,9 +232,9 @@ extern "C" __global__ __launch_bounds__(256) void pt_blend_rgba8_kernel(
 // The blend itself is static/shader.frag:387-404, operation for operation as pt_blend_rgba8_kernel.
 // --------------------------------------------------------------------------------------------
 extern "C" __global__ __launch_bounds__(256) void pt_frame_blend_kernel(
-    const float4* slab, uint32_t* tex0, uint32_t* tex1, uint32_t* canvas, uint32_t n_pix, const uint32_t* ctr,
+    const float4* slab, uint32_t* tex0, uint32_t* tex1, uint32_t* canvas, uint32_t n_pix, const uint32_t* ctr, uint32_t k_off,
     int render_count0, uint32_t even_odd0, int max_render_count, int should_average, float last_frame_weight) {
-  const uint32_t k = ctr[0];
+  const uint32_t k = ctr[0] + k_off;  // (k_off: this frame's place among the frames one launch has traced, pt_render_frames)
   const long long rc_ll = (long long)render_count0 + (long long)k;
   const int render_count = rc_ll < (long long)max_render_count ? (int)rc_ll : max_render_count;
   const uint32_t even_odd = even_odd0 + k;
@@ -267,10 +267,10 @@ extern "C" __global__ __launch_bounds__(256) void pt_frame_blend_kernel(
   }
 }
 
-// end of a frame: the next replay is frame k + 1, and its work queue starts at item 0
-extern "C" __global__ void pt_frame_advance_kernel(uint32_t* ctr, unsigned long long* queue_head) {
+// end of a replay of n frames: the next one starts at frame k + n, and its work queue at item 0
+extern "C" __global__ void pt_frame_advance_kernel(uint32_t* ctr, unsigned long long* queue_head, uint32_t n) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctr[0] += 1u;
+    ctr[0] += n;
     queue_head[0] = 0ull;
   }
 }

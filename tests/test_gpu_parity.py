@@ -675,14 +675,15 @@ def test_frame_loop_reference_mode_matches_oracle_simulation(ora):
 
 
 def test_frames_replayed_from_one_graph_match_single_ticks(ora):
-    """pt_render_frames: ONE captured frame (trace + blend + advance) replayed n times with u_time,
-    render_count and the even/odd texture choice counted on the device must draw what n single
-    ticks with host-made uniforms draw (pt_render_frame), which in turn is the oracle's simulation of
+    """pt_render_frames: captured frames replayed with u_time, render_count and the even/odd texture choice
+    counted on the device — in groups of eight (ONE trace launch renders the group's frames as its passes,
+    their blends follow in order) and one by one for the remainder — must draw what n single ticks with
+    host-made uniforms draw (pt_render_frame), which in turn is the oracle's simulation of
     src/lib.rs:65-104 + src/webgl.rs:180-205.  Interval and start time are exact in fp32, so the
-    device's time + float(k) * interval is the host's float(now_k)."""
+    device's time + float(k) * interval is the host's float(now_k).  n = 19: two groups and three singles."""
     from ray_tracer_webgl_amd.app import FrameLoop
 
-    w, h, n = 96, 54, 7
+    w, h, n = 96, 54, 19
     a = FrameLoop(w, h, mode="reference")
     a.state.set_flags(is_paused=False)
     a.state.set_quality(2, 8)
@@ -706,18 +707,20 @@ def test_frames_replayed_from_one_graph_match_single_ticks(ora):
     va, vb = a.state.view(), b.state.view()
     assert (va.render_count, va.even_odd_count) == (vb.render_count, vb.even_odd_count) == (n, n)
     assert b.tracer.stats().segments == a.tracer.stats().segments
-    # a second series continues where the first stopped (same graph, re-armed counter) ...
-    assert b.frames(3, 100.0 + 16.5 * n, 16.5) == 3
-    for k in range(n, n + 3):
+    # a second series continues where the first stopped (same graphs, re-armed counter) ...
+    assert b.frames(9, 100.0 + 16.5 * n, 16.5) == 9
+    for k in range(n, n + 9):
         assert a.frame(100.0 + 16.5 * k) is True
     assert np.array_equal(b.canvas, a.canvas)
+    tb = b.textures
+    assert np.array_equal(a.textures[0], tb[0]) and np.array_equal(a.textures[1], tb[1])
     # ... and a camera change between series re-captures with the new uniforms
     for loop in (a, b):
         loop.state.set_camera_angles(-75.0, 4.0)
-    assert b.frames(2, 500.0, 16.5) == 2
-    for k in range(2):
+    assert b.frames(10, 500.0, 16.5) == 10
+    for k in range(10):
         assert a.frame(500.0 + 16.5 * k) is True
-    assert np.array_equal(b.canvas, a.canvas) and b.state.view().render_count == 2
+    assert np.array_equal(b.canvas, a.canvas) and b.state.view().render_count == 10
     a.close()
     b.close()
 
