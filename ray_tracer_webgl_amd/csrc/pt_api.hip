@@ -1172,7 +1172,13 @@ int enqueue_frame(pt_ctx* c, FramePlan& F, bool advance) {
   // a frame's one pass sits in its slab ({sum r, g, b, spp} per pixel): blend straight from there, frame after frame
   // (each blend reads the texture the one before it wrote)
   const uint32_t n_pix = c->local_rows * c->width;
-  for (uint32_t f = 0; f < F.n_frames; f++) {
+  if (F.n_frames > 1u) {  // a group: its blends as one pass over the pixels
+    hipLaunchKernelGGL(pt_frames_blend_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream, F.slab, F.n_frames,
+                       c->d_tex[0], c->d_tex[1], c->d_canvas, n_pix, F.ctr, F.render_count0, F.even_odd0, F.max_render_count,
+                       F.should_average, F.last_frame_weight);
+    PT_HIP(c, hipGetLastError());
+  }
+  for (uint32_t f = 0; f < (F.n_frames > 1u ? 0u : 1u); f++) {
     hipLaunchKernelGGL(pt_frame_blend_kernel, dim3(grid_for(n_pix, 256, 2048)), dim3(256), 0, c->stream, F.slab + (size_t)f * n_pix,
                        c->d_tex[0], c->d_tex[1], c->d_canvas, n_pix, F.ctr, f, F.render_count0, F.even_odd0, F.max_render_count,
                        F.should_average, F.last_frame_weight);

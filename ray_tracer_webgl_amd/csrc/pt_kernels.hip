@@ -267,6 +267,55 @@ extern "C" __global__ __launch_bounds__(256) void pt_frame_blend_kernel(
   }
 }
 
+// The blends of a GROUP of frames in one pass over the pixels (pt_render_frames: the group's frames are the passes
+// of one trace launch, slab f = frame k + f).  A pixel's chain of blends touches no other pixel, so each thread runs
+// its pixel's n_frames blends one after the other — pt_frame_blend_kernel's rule, operation for operation and
+// quantised to RGBA8 after every frame exactly as the separate launches would leave it in the texture — and keeps
+// the previous frame's texel in a register instead of writing it and reading it back: with averaging on, frame
+// f reads the texture frame f - 1 wrote (the ping-pong pair has period two), so only the group's last two frames
+// reach memory, and the canvas shows the last.  Without averaging no frame writes a texture and every frame
+// blends against the same stored one.
+extern "C" __global__ __launch_bounds__(256) void pt_frames_blend_kernel(
+    const float4* slab, uint32_t n_frames, uint32_t* tex0, uint32_t* tex1, uint32_t* canvas, uint32_t n_pix, const uint32_t* ctr,
+    int render_count0, uint32_t even_odd0, int max_render_count, int should_average, float last_frame_weight) {
+  const uint32_t k0 = ctr[0];
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    uint32_t pv = 0u, o = 0u;
+    for (uint32_t f = 0; f < n_frames; f++) {
+      const uint32_t k = k0 + f;
+      const long long rc_ll = (long long)render_count0 + (long long)k;
+      const int render_count = rc_ll < (long long)max_render_count ? (int)rc_ll : max_render_count;
+      const float rc = (float)render_count;
+      const uint32_t even_odd = even_odd0 + k;
+      // the previous frame's texel: from memory for the group's first frame (and always when nothing is written
+      // back), from the register afterwards
+      if (f == 0u || !should_average) pv = (((even_odd + 1u) & 1u) ? tex1 : tex0)[i];
+      else pv = o;
+      const float4 v = slab[(size_t)f * n_pix + i];
+      const float scale = pixel_scale(v.w);
+      float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale), __builtin_sqrtf(v.z * scale)};
+      const float pa = (float)(pv >> 24) / 255.0f;
+      o = 255u << 24;
+      if (should_average && !(pa == 0.0f || render_count <= 1)) {
+        const float total = rc + last_frame_weight;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
+          const float merged = fma_(px[c], last_frame_weight, pr * rc) / total;
+          o |= unorm8(merged) << (8 * c);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
+      }
+      // what reaches memory: the last two frames' textures (earlier ones are overwritten by them), the last canvas
+      if (should_average && f + 2u >= n_frames) ((even_odd & 1u) ? tex1 : tex0)[i] = o;
+    }
+    canvas[i] = o;
+  }
+}
+
 // end of a replay of n frames: the next one starts at frame k + n, and its work queue at item 0
 extern "C" __global__ void pt_frame_advance_kernel(uint32_t* ctr, unsigned long long* queue_head, uint32_t n) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {

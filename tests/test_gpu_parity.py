@@ -856,6 +856,46 @@ def test_frames_while_the_autotuner_is_still_measuring(ora):
     b.close()
 
 
+@pytest.mark.parametrize("should_average", [1, 0])
+def test_a_group_of_frames_equals_its_single_ticks_at_the_abi(should_average):
+    """pt_render_frames at the C ABI, below FrameLoop: nine frames (a group of eight — one trace launch of eight
+    passes and ONE blend kernel that runs each pixel's eight blends in registers — and one single frame)
+    against nine pt_render_frame calls whose uniforms the host steps itself: time + k * interval (exact in
+    fp32), render_count clamped at max_render_count on the way, even_odd_count + k.  With averaging the
+    canvas and BOTH textures must agree (the group writes only its last two frames' textures: the others
+    would have been overwritten); without it no texture changes and the canvas shows the last frame unblended."""
+    sc = scenes.default_scene(96, 54, spp=1, max_depth=6)
+    n, t0, dt, rc0, rc_max, e0 = 9, 200.0, 16.5, 3, 7, 5
+    seed_tex = np.random.default_rng(5).integers(0, 256, (2, 54, 96, 4), dtype=np.uint8)
+    seed_tex[..., 3] = 255
+    out = []
+    for grouped in (True, False):
+        t = PathTracer(96, 54)
+        t.set_spheres(sc.spheres)
+        t.write_texture(0, seed_tex[0])
+        t.write_texture(1, seed_tex[1])
+        p = sc.params.copy()
+        p.should_average, p.last_frame_weight, p.render_count = should_average, 1.0, rc0
+        p.time, p.time_step, p.first_pass = t0, dt, 0
+        if grouped:
+            t.set_params(p)
+            t.render_frames(e0, rc_max, n)
+        else:
+            for k in range(n):
+                q = p.copy()
+                q.time, q.render_count = t0 + dt * k, min(rc0 + k, rc_max)
+                t.set_params(q)
+                t.render_frame(e0 + k)
+        out.append((t.read_canvas(), t.read_texture(0), t.read_texture(1), t.stats().segments))
+        t.close()
+    (ca, a0, a1, sa), (cb, b0, b1, sb) = out
+    assert sa == sb
+    assert np.array_equal(ca, cb), "canvas"
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1), "textures"
+    if not should_average:
+        assert np.array_equal(a0, seed_tex[0]) and np.array_equal(a1, seed_tex[1])
+
+
 def test_frame_entry_points_refuse_what_they_cannot_do():
     pt = PathTracer(16, 16)
     assert pt.lib.pt_render_frame(pt._ctx, 0) == abi.PT_ERR_NOT_READY  # no scene / uniforms yet
