@@ -1146,9 +1146,10 @@ int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_rende
   memset(static_cast<void*>(F), 0, sizeof *F);  // (padding too: plans are compared bytewise)
   // frames k .. k + n - 1 are the passes 0 .. n - 1 of ONE launch: pass p renders at u_time = time + float(first_pass + p + k) *
   // time_step (pt_refill.hpp), which IS frame k + p's time, into slab p
-  // (a group of frames is still a short launch of uniform items: dealt statically whatever its size, since the shared
-  // queue's atomics would cost more than the frames — 8 frames of the reference's size: 0.37 ms per frame with them)
-  int rc = prepare_launch(c, n_frames, false, &F->L, true);
+  // (a GROUP of frames is still a short launch of uniform items: dealt statically whatever its size, since the shared
+  // queue's atomics would cost more than the frames — 8 frames of the reference's size: 0.37 ms per frame with them; a single
+  // frame keeps the rule of every launch: statically below eight items per lane)
+  int rc = prepare_launch(c, n_frames, false, &F->L, n_frames > 1u);
   if (rc != PT_OK) return rc;
   F->L.A.frame_ctr = ctr;
   F->L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
