@@ -7,7 +7,7 @@ run_setters -> render -> (save).  Two display modes:
     textures (src/webgl.rs:186-204) — the reference's on-screen behaviour, 8-bit quantisation
     and gamma-space averaging included.  The textures live on the device (pt_render_frame); a run
     of ticks at a constant frame interval is replayed from hipGraphs (`frames`, pt_render_frames:
-    groups of eight frames traced by one launch) with the per-frame state counted on the device.
+    groups of 16 and 4 frames, each traced by one launch) with the per-frame state counted on the device.
   * "linear": passes accumulate as fp32 linear radiance (north_star's "accumulated radiance")
     and are resolved at read-out; a camera change (render_count reset to 0,
     src/state.rs:343-346) clears the accumulation.
@@ -109,7 +109,7 @@ class FrameLoop:
 def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device=0):
     """bench.py --config default: the reference at its own operating point (State::default, 9 spheres,
     1280x702 = images/14.png, depth 8; src/state.rs:127-135).  Times (i) the animation loop — 1 spp per
-    tick, blended into the RGBA8 textures, replayed from hipGraphs in groups of eight — and (ii) the 25-spp frames the
+    tick, blended into the RGBA8 textures, replayed from hipGraphs in groups of 16 — and (ii) the 25-spp frames the
     reference draws while paused (src/webgl.rs:342-346), plus (iii) the same ticks issued one by one
     from the host (uniform upload + three launches per frame) for comparison.  Returns the JSON dict."""
     from . import abi
@@ -120,7 +120,7 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
     n_sph = st.view().n_spheres
 
     def run(kind, n):
-        """kind: "graph" = the animation loop replayed from hipGraphs (groups of eight frames); "host" = the same ticks issued one
+        """kind: "graph" = the animation loop replayed from hipGraphs (groups of 16 and 4 frames); "host" = the same ticks issued one
         by one; "paused" = what the reference draws while paused: ONE 25-spp frame after every camera
         change (render_count == 0, src/lib.rs:77-82, src/webgl.rs:342-346) — here after a yaw nudge"""
         paused = kind == "paused"
@@ -154,7 +154,7 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
             "segments_per_frame": round(s.segments / n, 1),
             "device_ms_per_frame": round(s.render_kernel_ms / n, 4) if kind == "graph" else None,
             "geometry_path": abi.GEOM_NAMES.get(s.geometry_path, "?"),
-            "how": {"graph": "%d frames replayed from hipGraphs in groups of eight (one trace launch renders a group's frames as its passes, one "
+            "how": {"graph": "%d frames replayed from hipGraphs in groups of 16 and 4 (one trace launch renders a group's frames as its passes, one "
                              "kernel runs their blends, one advance), per-frame state on the device" % n,
                     "host": "uniform upload + trace + blend issued per frame from the host",
                     "paused": "one frame per camera change, issued from the host (uniform upload + trace + blend)"}[kind],

@@ -108,13 +108,13 @@ struct pt_ctx {
   uint32_t* d_canvas = nullptr;
   size_t tex_pixels = 0;
   uint32_t* d_frame_ctr = nullptr;
-  hipGraphExec_t frame_exec = nullptr;   // one frame (trace + blend + advance), captured once per plan (FramePlan below)
-  hipGraphExec_t frames_exec = nullptr;  // kFramesPerGraph frames: ONE trace launch of that many passes, their blends in order, advance
-  unsigned char frames_plan[1024] = {0};
-  float4* d_frame_slab = nullptr;        // the group's slabs (kFramesPerGraph passes), allocated by the first pt_render_frames that needs them
+  // captured frames, one graph per group size (kFrameGroups: 16, 4, 1 frames — a group is ONE trace launch of that many passes,
+  // one kernel for their blends, one advance; a single frame is trace + blend + advance), each captured once per plan
+  hipGraphExec_t frame_exec[3] = {nullptr, nullptr, nullptr};
+  unsigned char frame_plan[3][1024] = {{0}, {0}, {0}};  // the FramePlan each cached graph was captured from (compared bytewise)
+  float4* d_frame_slab = nullptr;        // a group's slabs (up to 16 passes), allocated by the first pt_render_frames that needs them
   size_t frame_slab_pixels = 0;
   uint64_t epoch = 0;                    // bumped by everything a captured frame bakes in
-  unsigned char frame_plan[1024] = {0};  // the FramePlan the cached graph was captured from (compared bytewise)
   // counters + timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // pool
@@ -150,10 +150,9 @@ int fail(pt_ctx* c, int code, const char* fmt, ...) {
 
 // frames per replayed graph (pt_render_frames; measured on the reference's 1280x702 1-spp frame: 1 / 2 / 4 / 8 / 16 / 32 frames
 // per graph -> 8 190 / 12 690 / 18 960 / 21 040 / 21 790 / 21 000 frames per second)
-#ifndef PT_FRAMES_PER_GRAPH
-#define PT_FRAMES_PER_GRAPH 8
-#endif
-constexpr uint32_t kFramesPerGraph = PT_FRAMES_PER_GRAPH;  // (dev A/B builds override it)
+// 960 frames with the group's blends as one kernel: 8 / 12 / 16 / 24 per graph -> 22 640 / 23 020 / 23 940 / 24 250; 16 it is (230 MB of slabs
+// at that size), with groups of 4 and single frames for what is left of a series
+constexpr uint32_t kFrameGroups[3] = {16u, 4u, 1u};
 
 uint32_t count_local_rows(uint32_t height, const PtParams& p) {
   return pt_local_rows(height, p.band_rows, p.band_index, p.band_count);
@@ -391,8 +390,7 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_slab) (void)hipFree(c->d_slab);
   if (c->d_resolve) (void)hipFree(c->d_resolve);
   if (c->d_counters) (void)hipFree(c->d_counters);
-  if (c->frame_exec) (void)hipGraphExecDestroy(c->frame_exec);
-  if (c->frames_exec) (void)hipGraphExecDestroy(c->frames_exec);
+  for (hipGraphExec_t e : c->frame_exec) if (e) (void)hipGraphExecDestroy(e);
   if (c->d_frame_slab) (void)hipFree(c->d_frame_slab);
   if (c->d_frame_ctr) (void)hipFree(c->d_frame_ctr);
   for (int k = 0; k < 2; k++) if (c->d_tex[k]) (void)hipFree(c->d_tex[k]);
@@ -1140,7 +1138,7 @@ struct FramePlan {
   uint32_t* tex0 = nullptr; uint32_t* tex1 = nullptr; uint32_t* canvas = nullptr;
   uint32_t n_frames = 1;  // frames traced by the one launch (as its passes), blended one after the other
 };
-static_assert(sizeof(FramePlan) <= sizeof(pt_ctx::frame_plan), "pt_ctx::frame_plan must hold a FramePlan");
+static_assert(sizeof(FramePlan) <= sizeof(pt_ctx::frame_plan[0]), "pt_ctx::frame_plan must hold a FramePlan");
 
 int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_render_count, uint32_t n_frames, float4* slab, FramePlan* F) {
   memset(static_cast<void*>(F), 0, sizeof *F);  // (padding too: plans are compared bytewise)
@@ -1256,13 +1254,18 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     return fail(c, PT_ERR_INVALID, "pt_render_frames: the context runs on the legacy default stream (PT_STREAM_LEGACY), which cannot be "
                                    "captured into a hipGraph; give it a stream of its own (pt_set_stream(ctx, NULL) or a created stream) "
                                    "or issue the ticks with pt_render_frame");
-  // Frames in groups of kFramesPerGraph: ONE trace launch renders the group's frames as its passes (each pass has its own
-  // u_time: the frame's), then their blends run in order.  A 1-spp frame of the reference's size is two items per resident
-  // lane, and a wave ends when its slowest lane does: most of a single frame's 0.11 ms is that drain; four frames in one
-  // launch share one.  The remainder of the series is replayed frame by frame.  Same bits either way: a frame is a pass.
-  const uint32_t per_group = n_frames >= kFramesPerGraph ? kFramesPerGraph : 1u;
-  if (per_group > 1u) {  // the group's own slabs (never the slab of pt_render_passes: a caller's captured launches keep theirs)
-    const size_t need = (size_t)c->local_rows * c->width * per_group;
+  // Frames in GROUPS of 16 and 4: ONE trace launch renders a group's frames as its passes (each pass has its own u_time: the
+  // frame's), one kernel runs their blends in order.  A 1-spp frame of the reference's size is two items per resident lane,
+  // and a wave ends when its slowest lane does: most of a single frame's 0.11 ms is that drain; a group shares one.  What is
+  // left of the series is replayed frame by frame.  Same bits either way: a frame is a pass.
+  uint32_t counts[3] = {0, 0, 0};
+  {
+    uint32_t left = n_frames;
+    for (int g = 0; g < 3; g++) { counts[g] = left / kFrameGroups[g]; left -= counts[g] * kFrameGroups[g]; }
+  }
+  const uint32_t biggest = counts[0] ? kFrameGroups[0] : (counts[1] ? kFrameGroups[1] : 1u);
+  if (biggest > 1u) {  // the groups' own slabs (never the slab of pt_render_passes: a caller's captured launches keep theirs)
+    const size_t need = (size_t)c->local_rows * c->width * biggest;
     if (c->frame_slab_pixels < need) {  // first use at this size: the one allocation this entry point ever makes
       PT_HIP(c, hipStreamSynchronize(c->stream));
       if (c->d_frame_slab) PT_HIP(c, hipFree(c->d_frame_slab));
@@ -1275,7 +1278,10 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
   if (rc != PT_OK) return rc;
   // everything a graph bakes in is decided outside the capture; a cached graph is reused while that is unchanged
   // (pt_set_params with the same values, as a frame loop issues before every series, does not re-capture)
-  auto graph_for = [&](uint32_t frames, hipGraphExec_t* exec, unsigned char* plan_store) -> int {
+  auto graph_for = [&](int g) -> int {
+    const uint32_t frames = kFrameGroups[g];
+    hipGraphExec_t* exec = &c->frame_exec[g];
+    unsigned char* plan_store = c->frame_plan[g];
     FramePlan F;
     int r = plan_frame(c, c->d_frame_ctr, even_odd_count, (int)max_render_count, frames, frames > 1u ? c->d_frame_slab : c->d_slab, &F);
     if (r != PT_OK) return r;
@@ -1293,10 +1299,8 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     memcpy(static_cast<void*>(plan_store), &F, sizeof F);
     return PT_OK;
   };
-  const uint32_t n_groups = per_group > 1u ? n_frames / per_group : 0u;
-  const uint32_t n_single = n_frames - n_groups * per_group;
-  if (n_groups) { rc = graph_for(per_group, &c->frames_exec, c->frames_plan); if (rc != PT_OK) return rc; }
-  if (n_single) { rc = graph_for(1u, &c->frame_exec, c->frame_plan); if (rc != PT_OK) return rc; }
+  for (int g = 0; g < 3; g++)
+    if (counts[g]) { rc = graph_for(g); if (rc != PT_OK) return rc; }
   // the series starts at frame 0 with an empty queue; every replay leaves both ready for the next
   PT_HIP(c, hipMemsetAsync(c->d_frame_ctr, 0, sizeof(uint32_t), c->stream));
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
@@ -1314,8 +1318,8 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
   }
   std::pair<hipEvent_t, hipEvent_t>& ev = c->events[c->events_used++];
   PT_HIP(c, hipEventRecord(ev.first, c->stream));
-  for (uint32_t g = 0; g < n_groups; g++) PT_HIP(c, hipGraphLaunch(c->frames_exec, c->stream));
-  for (uint32_t k = 0; k < n_single; k++) PT_HIP(c, hipGraphLaunch(c->frame_exec, c->stream));
+  for (int g = 0; g < 3; g++)
+    for (uint32_t k = 0; k < counts[g]; k++) PT_HIP(c, hipGraphLaunch(c->frame_exec[g], c->stream));
   PT_HIP(c, hipEventRecord(ev.second, c->stream));
   c->launches += n_frames;
   c->samples += (uint64_t)n_frames * c->local_rows * c->width * (uint64_t)c->params.samples_per_pixel;

@@ -676,11 +676,11 @@ def test_frame_loop_reference_mode_matches_oracle_simulation(ora):
 
 def test_frames_replayed_from_one_graph_match_single_ticks(ora):
     """pt_render_frames: captured frames replayed with u_time, render_count and the even/odd texture choice
-    counted on the device — in groups of eight (ONE trace launch renders the group's frames as its passes,
+    counted on the device — in groups of 16 and 4 (ONE trace launch renders a group's frames as its passes,
     their blends follow in order) and one by one for the remainder — must draw what n single ticks with
     host-made uniforms draw (pt_render_frame), which in turn is the oracle's simulation of
     src/lib.rs:65-104 + src/webgl.rs:180-205.  Interval and start time are exact in fp32, so the
-    device's time + float(k) * interval is the host's float(now_k).  n = 19: two groups and three singles."""
+    device's time + float(k) * interval is the host's float(now_k).  n = 19: a group of 16 and three singles; then 9 = 4 + 4 + 1 and 10 = 4 + 4 + 1 + 1."""
     from ray_tracer_webgl_amd.app import FrameLoop
 
     w, h, n = 96, 54, 19
@@ -858,8 +858,8 @@ def test_frames_while_the_autotuner_is_still_measuring(ora):
 
 @pytest.mark.parametrize("should_average", [1, 0])
 def test_a_group_of_frames_equals_its_single_ticks_at_the_abi(should_average):
-    """pt_render_frames at the C ABI, below FrameLoop: nine frames (a group of eight — one trace launch of eight
-    passes and ONE blend kernel that runs each pixel's eight blends in registers — and one single frame)
+    """pt_render_frames at the C ABI, below FrameLoop: nine frames (two groups of four — each one trace launch of four
+    passes and ONE blend kernel that runs each pixel's four blends in registers — and one single frame)
     against nine pt_render_frame calls whose uniforms the host steps itself: time + k * interval (exact in
     fp32), render_count clamped at max_render_count on the way, even_odd_count + k.  With averaging the
     canvas and BOTH textures must agree (the group writes only its last two frames' textures: the others
