@@ -194,8 +194,10 @@ __device__ __forceinline__ void list_scan(const PtKernelArgs& A, const Path& p, 
 // (no re-gather, no re-test) — in ascending list order, so the acceptance is the shader's own
 // sequential rule (:159-161): accept iff MIN_T <= v <= closest-so-far, which hands ties to the
 // LATER sphere exactly as the shader's loop does.  A candidate is skipped only when the shader
-// would reject it too (discriminant < 0, or both roots <= 0: see the note at the top).  Padding
-// entries (index >= n) are masked.  Regular rays only; the others take the literal loop.
+// would reject it too (discriminant < 0, or both roots <= 0: see the note at the top).  The builds for a
+// known list remainder (S::SMALL_TAIL = n mod 4, pt_kernels_small.hip) test exactly the n spheres; the build for
+// any length (SMALL_TAIL < 0: the opt-in twin) tests the last group's padding entries and masks them.  Regular rays
+// only; the others take the literal loop.
 template <typename S>
 __device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p, bool scan_lane, Hit& h) {
   const V3 o = p.o; const V3 d = p.d; const float a = p.a;

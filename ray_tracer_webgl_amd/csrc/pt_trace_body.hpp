@@ -1,6 +1,7 @@
-// pt_trace_body.hpp — the path-tracing kernel body shared by the two device translation units:
-// pt_kernels.hip (the kernels every context uses) and pt_kernels_extra.hip (the opt-in builds: the
-// Russian-roulette kernels and the measuring twins — a code object of its own, loaded only when asked for).
+// pt_trace_body.hpp — the path-tracing kernel body shared by the three device translation units (each a gfx950
+// code object of its own, loaded when one of its kernels is first asked for): pt_kernels.hip (list and walk
+// kernels), pt_kernels_small.hip (the small-list kernels, one per list length modulo four) and
+// pt_kernels_extra.hip (the opt-in builds: the Russian-roulette kernels and the measuring twins).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
