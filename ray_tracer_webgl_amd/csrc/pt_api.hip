@@ -986,6 +986,16 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   {
     const unsigned long long lanes = (unsigned long long)c->num_cus * (unsigned)per_cu * block;
     A.queue_chunk = items >= 192ull * lanes ? 512u : (items >= 64ull * lanes ? 128u : (items >= 16ull * lanes ? 64u : 32u));
+    // ... and to the ITEMS (round 4): the queue head is one address and takes a reservation every ~13 ns (77 M/s: a 16-pass
+    // launch of 1-spp items at the reference's size never ran faster than 2.9 ms through it, 0.65 ms dealt statically); an item
+    // of s samples is ~s x 27 us of a lane's time, so reservations of at least 1100 / s items keep the head below half
+    // of that rate
+    {
+      const uint32_t spp = (uint32_t)(c->params.samples_per_pixel > 0 ? c->params.samples_per_pixel : 1);
+      uint32_t c_min = 32u;
+      while (c_min * spp < 1100u && c_min < 1024u) c_min *= 2u;
+      if (A.queue_chunk < c_min) A.queue_chunk = c_min;
+    }
 #ifdef PT_DEV_KNOBS
     if (const char* e = getenv("PT_QUEUE_CHUNK")) {
       uint32_t v = (uint32_t)atoi(e);
@@ -1003,7 +1013,15 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   // items round-robin to the waves instead (no atomic; the cost-ordered tile list still spreads the
   // heavy tiles over the waves).
   A.n_waves = grid * (block / 64u);
-  A.queue_static = (deal_statically || items < 8ull * (unsigned long long)A.n_waves * 64ull) ? 1u : 0u;
+  // ... and items of one or two samples up to 64 items per lane (16 passes of 1 / 2 spp at the reference's size: 0.65 / 1.14 ms
+  // against 2.89 / 2.89 through the queue, whose head was the limit; with 4-spp items static dealing costs the cover scene
+  // +14 % — its long paths need the queue's balance — so those keep the queue, with reservations sized as above:
+  // 2.96 -> 1.84 ms; tools/queue_shapes.py, profiles/r04_ab_runs.txt)
+  const bool short_items = c->params.samples_per_pixel <= 2 && items < 64ull * (unsigned long long)A.n_waves * 64ull;
+  A.queue_static = (deal_statically || short_items || items < 8ull * (unsigned long long)A.n_waves * 64ull) ? 1u : 0u;
+#ifdef PT_DEV_KNOBS
+  if (const char* e = getenv("PT_QUEUE_STATIC")) A.queue_static = atoi(e) ? 1u : 0u;
+#endif
   if (A.queue_static) A.queue_chunk = 64u;
 
   L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;

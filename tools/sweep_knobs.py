@@ -8,12 +8,14 @@ def child():
     from ray_tracer_webgl_amd import abi, scenes
     from ray_tracer_webgl_amd.tracer import PathTracer
     spp, n = int(os.environ.get("SW_SPP", "16")), int(os.environ.get("SW_PASSES", "64"))
-    if os.environ.get("SW_CONFIG", "config2") == "config5":
+    if os.environ.get("SW_CONFIG", "config2") == "default":  # State::default at the reference's size, depth 8
+        sc = scenes.default_scene(1280, 702, spp, 8, n)
+    elif os.environ.get("SW_CONFIG", "config2") == "config5":
         sc = scenes.config5(1920, 1080, spp, n, 50)
     else:
         sc = scenes.config2(1920, 1080, spp, n, 50)
     sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
-    pt = PathTracer(1920, 1080)
+    pt = PathTracer(sc.params.width, sc.params.height)
     pt.set_geometry_path(int(os.environ.get("SW_PATH", abi.PT_GEOM_GRID)))
     if os.environ.get("SW_CARRY"): pt.set_carry_lanes(int(os.environ["SW_CARRY"]))
     if os.environ.get("SW_REFILL"): pt.set_refill_min(int(os.environ["SW_REFILL"]))
