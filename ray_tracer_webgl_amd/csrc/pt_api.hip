@@ -1022,7 +1022,13 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
 #ifdef PT_DEV_KNOBS
   if (const char* e = getenv("PT_QUEUE_STATIC")) A.queue_static = atoi(e) ? 1u : 0u;
 #endif
-  if (A.queue_static) A.queue_chunk = 64u;
+  if (A.queue_static) {
+    A.queue_chunk = 64u;
+    // a statically dealt launch of ONE-sample items keeps the tile order it finds: the feedback's one atomic per pixel of pass 0
+    // costs such a launch more than the order gives it (4 passes of 1 spp at the reference's size: 0.206 -> 0.185 ms; with 2, 4, 8
+    // spp the cost-ordered tiles pay: 0.318 / 0.557 / 1.03 ms with feedback against 0.333 / 0.608 / 1.13 without)
+    if (c->params.samples_per_pixel < 2) A.cost_feedback = 0u;
+  }
 
   L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;
   return PT_OK;
@@ -1088,7 +1094,8 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   }
   std::pair<hipEvent_t, hipEvent_t>* ev = capturing ? nullptr : &c->events[c->events_used++];
 
-  PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  if (!A.queue_static)  // (a statically dealt launch takes no reservations from the shared head)
+    PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
   // queue order from the previous launch's per-tile cost (identity when there is none yet); launches
   // that report no cost keep the order they find
   if (A.cost_feedback || !c->tile_order_valid) {
