@@ -1006,6 +1006,9 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   const unsigned long long want = (items + block - 1) / block;
   const unsigned long long resident = (unsigned long long)c->num_cus * (unsigned)per_cu;
   uint32_t grid = (uint32_t)(want < resident ? want : resident);
+#ifdef PT_DEV_KNOBS
+  if (const char* e = getenv("PT_GRID_PERCENT")) grid = (uint32_t)((unsigned long long)grid * (unsigned)atoi(e) / 100ull);
+#endif
   if (grid < 1) grid = 1;
   // Launches of a few items per lane (the reference's 1-spp frame: two) cannot afford the shared
   // queue: its head is ONE address, the reservations' atomics take their turn there (~25 ns each), and
@@ -1021,6 +1024,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   A.queue_static = (deal_statically || short_items || items < 8ull * (unsigned long long)A.n_waves * 64ull) ? 1u : 0u;
 #ifdef PT_DEV_KNOBS
   if (const char* e = getenv("PT_QUEUE_STATIC")) A.queue_static = atoi(e) ? 1u : 0u;
+  if (const char* e = getenv("PT_COST_FEEDBACK")) A.cost_feedback = atoi(e) ? 1u : 0u;
 #endif
   if (A.queue_static) {
     A.queue_chunk = 64u;
@@ -1028,6 +1032,18 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     // costs such a launch more than the order gives it (4 passes of 1 spp at the reference's size: 0.206 -> 0.185 ms; with 2, 4, 8
     // spp the cost-ordered tiles pay: 0.318 / 0.557 / 1.03 ms with feedback against 0.333 / 0.608 / 1.13 without)
     if (c->params.samples_per_pixel < 2) A.cost_feedback = 0u;
+    // FEWER WAVES for the shortest launches.  A launch of a lane-step or two per resident lane is all drain: a wave ends when
+    // its slowest lane does, and with fewer waves on a SIMD each step is faster and each wave deals more items to its lanes.
+    // One-sample items want ~4.6 per lane, two-sample items ~3.4 (the reference's 1280x702 frame, 1 spp: 0.115 -> 0.081 ms
+    // with 43 % of the resident workgroups; 2 spp: 0.132 -> 0.116 with 58 %; from 4 spp on the full grid wins).  Scheduling only.
+    if (c->params.samples_per_pixel <= 2) {
+      const unsigned long long per_wg = (unsigned long long)block * (c->params.samples_per_pixel == 1 ? 46ull : 34ull) / 10ull;
+      const unsigned long long fewer = (items + per_wg - 1) / per_wg;
+      if (fewer >= 1 && fewer < grid) {
+        grid = (uint32_t)fewer;
+        A.n_waves = grid * (block / 64u);
+      }
+    }
   }
 
   L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;
