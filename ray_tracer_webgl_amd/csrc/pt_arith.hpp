@@ -210,7 +210,18 @@ __device__ __forceinline__ float hit_root(float half_b, float disc, float a, flo
   return v;
 }
 
-// static/shader.frag:114-121
+// static/shader.frag:114-121, from the hash of its seed step (n = seed_step_hash(seed)): hash3's three numbers :32-36
+__device__ __forceinline__ V3 random_in_unit_sphere_from(uint32_t n) {
+  const float h0 = (float)(n & 0x7fffffffu) * (1.0f / 2147483648.0f);
+  const float h1 = (float)((n * 16807u) & 0x7fffffffu) * (1.0f / 2147483648.0f);
+  const float h2 = (float)((n * 48271u) & 0x7fffffffu) * (1.0f / 2147483648.0f);
+  float hx = fma_(h0, 2.0f, -1.0f);
+  float sp, cp;
+  sincos2pi(h1, sp, cp);
+  float r = cbrt_(h2);
+  float sq = sqrt_rn(fma_(-hx, hx, 1.0f));
+  return mk(r * (sq * sp), r * (sq * cp), r * hx);
+}
 __device__ __forceinline__ V3 random_in_unit_sphere(float& seed) {
   float h0, h1, h2;
   hash3(seed, h0, h1, h2);

@@ -30,18 +30,15 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
   (void)hit_pos;
   item_segs++;
   bool finished = false; // this camera path is over
-  if (hit < 0) {
-    if (A.background_mode == 0) { // background(), :289-294
-      float inv = inv_sqrt_rn(a);
-      float uy = d.y * inv;
-      float t = 0.5f * (uy + 1.0f);
-      float omt = 1.0f - t;
-      sum.x += col.x * fma_(0.5f, t, omt);
-      sum.y += col.y * fma_(0.7f, t, omt);
-      sum.z += col.z * fma_(1.0f, t, omt);
-    }
-    finished = true;
-  } else {
+  // ONE copy of what several outcomes share.  The lanes of a wave end their segments differently (sky, DIFFUSE,
+  // METAL, GLASS ...) and a wave runs every branch some lane takes: the sky and GLASS both want 1 / sqrt(|d|^2), and
+  // DIFFUSE, METAL and GLASS all begin their draw with the same seed step + hash.  Both are computed once, in straight
+  // line for every lane (no lane masks to set up and restore: a region costs more scalar work than it saves vector work;
+  // the seed moves only for the lanes that draw): State::default -1.4 %, config 5 -0.6 %, configs 2 and 4 +-0.1 %
+  // (profiles/r04_ab_runs.txt).
+  int mtype = -1;
+  V3 hp = mk(0.f, 0.f, 0.f), n = hp, alb = hp; bool front = false; float fuzz = 0.f, ri = 1.f;
+  if (hit >= 0) {
     float4 g;
     if constexpr (S::TREE) { // the walk's hits come with their slot (same four floats as the list entry)
       if (hit_pos != 0xffffffffu) g = S::slot_at(A, hit_pos);
@@ -55,14 +52,11 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
     }
     float4 m0 = mp[0]; // albedo.xyz, fuzz
     float4 m1 = mp[1]; // refraction_index, type, radius, uuid
-    int mtype = __float_as_int(m1.y);
+    mtype = __float_as_int(m1.y);
     float radius = m1.z;
-    // hit record, :166-171
-    V3 p = mk(fma_(d.x, closest, o.x), fma_(d.y, closest, o.y), fma_(d.z, closest, o.z));
-    // outward normal (p - centre) / radius, :168: three divisions by one denominator.  Fast form
-    // when |radius| is in [2^-20, 2^20) and every numerator has 2^-103 <= |n| < 2^76 (a zero
-    // numerator takes the plain operator: its quotient's sign of zero comes from v_div_fixup)
-    const float nx = p.x - g.x, ny = p.y - g.y, nz = p.z - g.z;
+    fuzz = m0.w; ri = m1.x;
+    hp = mk(fma_(d.x, closest, o.x), fma_(d.y, closest, o.y), fma_(d.z, closest, o.z)); // hit record, :166-171
+    const float nx = hp.x - g.x, ny = hp.y - g.y, nz = hp.z - g.z; // outward normal (p - centre) / radius, :168 (see above)
     V3 on;
     const float n_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
     const float n_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
@@ -73,12 +67,29 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
     if (__builtin_expect(pt_ballot(n_odd) != 0ull, 0)) { // (rare)
       if (n_odd) on = mk(nx / radius, ny / radius, nz / radius);
     }
-    bool front = dot3(d, on) < 0.0f; // :137
-    V3 n = front ? on : mk(-on.x, -on.y, -on.z);
-    V3 alb = mk(m0.x, m0.y, m0.z);
-
+    front = dot3(d, on) < 0.0f; // :137
+    n = front ? on : mk(-on.x, -on.y, -on.z);
+    alb = mk(m0.x, m0.y, m0.z);
+  }
+  const bool sky = hit < 0 && A.background_mode == 0;
+  const float inv = inv_sqrt_rn(a); // background() :290, GLASS :253
+  float seed_drawn = seed;
+  const uint32_t draw = seed_step_hash(seed_drawn); // DIFFUSE :217, METAL :240 (hash3), GLASS :267 (hash1)
+  seed = (uint32_t)mtype <= 2u ? seed_drawn : seed;
+  if (hit < 0) {
+    if (sky) { // background(), :289-294
+      float uy = d.y * inv;
+      float t = 0.5f * (uy + 1.0f);
+      float omt = 1.0f - t;
+      sum.x += col.x * fma_(0.5f, t, omt);
+      sum.y += col.y * fma_(0.7f, t, omt);
+      sum.z += col.z * fma_(1.0f, t, omt);
+    }
+    finished = true;
+  } else {
+    const V3 p = hp;
     if (mtype == 0 || mtype == 1) {
-      V3 rs = random_in_unit_sphere(seed); // both DIFFUSE (:217) and METAL (:240) draw one
+      V3 rs = random_in_unit_sphere_from(draw); // both DIFFUSE (:217) and METAL (:240) draw one
       V3 nd;
       bool ok = true;
       if (mtype == 0) { // DIFFUSE :212-229
@@ -86,7 +97,6 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
         nd = mk(n.x + ruv.x, n.y + ruv.y, n.z + ruv.z);
       } else { // METAL :232-247
         V3 refl = reflect3(d, n);
-        float fuzz = m0.w;
         nd = mk(fma_(fuzz, rs.x, refl.x), fma_(fuzz, rs.y, refl.y), fma_(fuzz, rs.z, refl.z));
         ok = dot3(n, nd) > 0.0f;
       }
@@ -97,16 +107,14 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
         finished = true; // absorbed: return vec3(0.) :327-329
       }
     } else if (mtype == 2) { // GLASS :250-282
-      float ri = m1.x;
       float ratio = front ? (1.0f / ri) : ri;
-      float inv = inv_sqrt_rn(a);
       V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
       float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
       float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
       float sin_theta = sqrt_rn(fma_(-cos_theta, cos_theta, 1.0f));
       bool cannot_refract = ratio * sin_theta > 1.0f;
       float refl_amount = reflectance(cos_theta, ratio);
-      float rnd = hash1(seed);
+      float rnd = (float)draw * (1.0f / 4294967296.0f); // hash1 :21-24
       V3 nd;
       if (cannot_refract || refl_amount > rnd) {
         nd = reflect3(ud, n);
@@ -129,7 +137,6 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
     } else {
       finished = true; // unrecognised material absorbs, :284-285
     }
-
     if (!finished) {
       a = dot3(d, d);
       depth++;
