@@ -24,15 +24,21 @@ __global__ __launch_bounds__(256) void chain(unsigned long long* out, float seed
   for (int i = 0; i < 4; i++) lds[threadIdx.x * 4 + i] = ((threadIdx.x * 4 + i) * 4u + 16u) & 4095u;
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  // (each chain is ONE asm statement — `.rept 64` — so that the compiler puts nothing between its instructions: between
+  // separate asm statements it inserts an s_nop)
   for (int it = 0; it < iters; it++) {
-    if (KIND == 0) { REP64(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(k));) }
-    if (KIND == 1) { REP64(asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(a), "+v"(b) : "v"(m), "v"(k));) }
-    if (KIND == 2) { REP64(asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(k));) }
-    if (KIND == 3) { REP64(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a) : "v"(m), "v"(b) : "vcc");) }
-    if (KIND == 4) { REP64(asm volatile("v_rcp_f32 %0, %0" : "+v"(a));) }
-    if (KIND == 5) { REP64(asm volatile("ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(idx) : : "memory");) }
-    if (KIND == 6) { REP64(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\ts_and_b64 s[20:21], vcc, exec\n\ts_cbranch_scc0 1f\n\tv_add_f32 %0, %0, %2\n1:" : "+v"(a) : "v"(m), "v"(k) : "vcc", "s20", "s21", "scc");) }
-    if (KIND == 7) { REP64(asm volatile("v_mul_f32 %0, %0, %1\n\tv_readfirstlane_b32 s20, %0\n\ts_add_u32 s20, s20, 1\n\tv_add_f32 %0, s20, %0" : "+v"(a) : "v"(m) : "s20", "scc");) }
+    if (KIND == 0) asm volatile(".rept 64\n\tv_fma_f32 %0, %0, %1, %2\n\t.endr" : "+v"(a) : "v"(m), "v"(k));
+    if (KIND == 1) asm volatile(".rept 64\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\t.endr" : "+v"(a), "+v"(b) : "v"(m), "v"(k));
+    if (KIND == 2) asm volatile(".rept 64\n\tv_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5\n\t.endr" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(k));
+    if (KIND == 3) asm volatile(".rept 64\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc\n\t.endr" : "+v"(a) : "v"(m), "v"(b) : "vcc");
+    if (KIND == 4) asm volatile(".rept 64\n\tv_rcp_f32 %0, %0\n\t.endr" : "+v"(a));
+    if (KIND == 5) asm volatile(".rept 64\n\tds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\t.endr" : "+v"(idx) : : "memory");
+    if (KIND == 6) asm volatile(".rept 64\n\tv_cmp_lt_f32 vcc, %0, %1\n\ts_and_b64 s[20:21], vcc, exec\n\ts_cbranch_scc0 1f\n\tv_add_f32 %0, %0, %2\n1:\n\t.endr" : "+v"(a) : "v"(m), "v"(k) : "vcc", "s20", "s21", "scc");
+    if (KIND == 7) asm volatile(".rept 64\n\tv_mul_f32 %0, %0, %1\n\tv_readfirstlane_b32 s20, %0\n\ts_add_u32 s20, s20, 1\n\tv_add_f32 %0, s20, %0\n\t.endr" : "+v"(a) : "v"(m) : "s20", "scc");
+    if (KIND == 8) asm volatile(".rept 64\n\tv_cmp_lt_f32 vcc, %0, %1\n\ts_cbranch_vccz 1f\n\tv_add_f32 %0, %0, %2\n1:\n\t.endr" : "+v"(a) : "v"(m), "v"(k) : "vcc");
+    if (KIND == 9) asm volatile(".rept 64\n\tv_cmp_lt_f32 vcc, %0, %1\n\ts_and_saveexec_b64 s[20:21], vcc\n\tv_add_f32 %0, %0, %2\n\ts_or_b64 exec, exec, s[20:21]\n\t.endr" : "+v"(a) : "v"(m), "v"(k) : "vcc", "s20", "s21", "scc");
+    if (KIND == 10) asm volatile(".rept 64\n\ts_add_u32 s20, s20, 1\n\t.endr" : : : "s20", "scc");
+    if (KIND == 11) asm volatile(".rept 64\n\ts_load_dword s20, %0, 0x0\n\ts_waitcnt lgkmcnt(0)\n\t.endr" : : "s"(out) : "s20", "memory");
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -95,5 +101,9 @@ int main(int argc, char** argv) {
   run<5>("ds_read_b32 dependent + wait", 1);
   run<6>("v_cmp, s_and, s_cbranch, v_add", 4);
   run<7>("v_mul, readfirstlane, s_add, v_add", 4);
+  run<8>("v_cmp, s_cbranch_vccz, v_add", 3);
+  run<9>("v_cmp, s_and_saveexec, v_add, s_or", 4);
+  run<10>("s_add_u32 dependent", 1);
+  run<11>("s_load_dword + wait (K$ hit)", 1);
   return 0;
 }
