@@ -121,7 +121,6 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
     }
   }
-
   tally.always_group(false);
   tally.phase(2);
   // per-ray constants of the walk (recomputed for carried lanes: cheaper than keeping them)
@@ -204,30 +203,38 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     // exit time, and steps on; it leaves this loop with a non-empty cell or with its walk over
     // (ballots of single compares, joined as masks: a ballot of `a && b` goes through a VGPR)
     unsigned long long m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
-    while (m_mv != 0ull) {
-      tally.walk(m_mv);
-      if (rem != 0u && pend < 0x1000000u) {
-        const uint32_t rec = S::cell_at(A, cell);
-        const float tmin = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
-        const bool isx = tmx == tmin;
-        const bool isy = !isx && tmy == tmin;
-        const bool isz = !isx && !isy;
-        t_exit = tmin;
-        pend = rec;
-        tmx += isx ? tdx : 0.0f;
-        tmy += isy ? tdy : 0.0f;
-        tmz += isz ? tdz : 0.0f;
-        const uint32_t dec = isx ? 1u : (isy ? 1024u : 1048576u);
-        rem -= dec;
-        const bool out = (rem & (dec * 1023u)) == 0u;
-        cell += (uint32_t)(isx ? sdx : (isy ? sdy : sdz));
-        // the walk is over when it leaves the grid — or, on an empty cell, when the closest
-        // root so far lies strictly before this cell's exit (a non-empty cell asks again
-        // after its entries have been tested)
-        rem = (out || ((rec >> 24) == 0u && closest < tmin)) ? 0u : rem;
-      }
+    // The FIRST cell step is written out in front of the loop: one step per leaf round is the common case, and a TAKEN
+    // branch is a ~30-tick bubble in its wave (tools/micro/valu_chain.hip) — the loop as the compiler lays it out takes
+    // three (entry, back-edge, exit) for its one trip, this form none: config 2 -0.8 %, a band of eight -1.4 %, config 5
+    // -1.2 % (profiles/r04_ab_runs.txt).
+#define PT_CELL_STEP \
+        tally.walk(m_mv); \
+        if (rem != 0u && pend < 0x1000000u) { \
+          const uint32_t rec = S::cell_at(A, cell); \
+          const float tmin = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz); \
+          const bool isx = tmx == tmin; \
+          const bool isy = !isx && tmy == tmin; \
+          const bool isz = !isx && !isy; \
+          t_exit = tmin; \
+          pend = rec; \
+          tmx += isx ? tdx : 0.0f; \
+          tmy += isy ? tdy : 0.0f; \
+          tmz += isz ? tdz : 0.0f; \
+          const uint32_t dec = isx ? 1u : (isy ? 1024u : 1048576u); \
+          rem -= dec; \
+          const bool out = (rem & (dec * 1023u)) == 0u; \
+          cell += (uint32_t)(isx ? sdx : (isy ? sdy : sdz)); \
+          rem = (out || ((rec >> 24) == 0u && closest < tmin)) ? 0u : rem; \
+        }
+    if (m_mv != 0ull) {
+      PT_CELL_STEP
       m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
+      while (__builtin_expect(m_mv != 0ull, 0)) {
+        PT_CELL_STEP
+        m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
+      }
     }
+#undef PT_CELL_STEP
     tally.phase(4);
     const bool has = (pend >> 24) != 0u;
     const unsigned long long m_has = pt_ballot(has);

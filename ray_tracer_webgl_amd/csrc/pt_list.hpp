@@ -212,20 +212,29 @@ __device__ __forceinline__ void small_scan(const PtKernelArgs& A, const Path& p,
   // the candidates of one group (mask: one bit per sphere of the group), finished in lockstep from the values still in
   // registers, in ascending list order
   auto finish = [&](uint32_t base, uint32_t mask, float hb0, float hb1, float hb2, float hb3, float ds0, float ds1, float ds2, float ds3) {
-    for (;;) {
-      if (pt_ballot(mask != 0u) == 0ull) break;
-      if (mask != 0u) {
-        const uint32_t k = first_candidate(mask); // ascending list order
-        mask &= mask - 1u;
-        const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3));
-        const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3));
-        const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161
-        if (!(v < PT_MIN_T) && v <= closest) { // :159-161, sequentially: a later sphere at the same root wins
-          closest = v;
-          hit = (int)(base + k);
-        }
+    // (the first evaluation in front of the loop: a TAKEN branch is a ~30-tick bubble in its wave, and a group with one
+    // candidate per lane — the common case — now runs through without one: config 4 -2.3 %, State::default -0.9 %)
+    // One evaluation: the lane's first remaining candidate (ascending list order), hit_root :156-161, accepted as the
+    // shader does sequentially (:159-161: a later sphere at the same root wins).
+#define PT_FINISH_STEP \
+      if (mask != 0u) { \
+        const uint32_t k = first_candidate(mask); \
+        mask &= mask - 1u; \
+        const float half_b = k == 0u ? hb0 : (k == 1u ? hb1 : (k == 2u ? hb2 : hb3)); \
+        const float disc = k == 0u ? ds0 : (k == 1u ? ds1 : (k == 2u ? ds2 : ds3)); \
+        const float v = hit_root(half_b, disc, a, ya, a_guard); \
+        if (!(v < PT_MIN_T) && v <= closest) { \
+          closest = v; \
+          hit = (int)(base + k); \
+        } \
+      }
+    if (pt_ballot(mask != 0u) != 0ull) {
+      PT_FINISH_STEP
+      while (pt_ballot(mask != 0u) != 0ull) {
+        PT_FINISH_STEP
       }
     }
+#undef PT_FINISH_STEP
   };
   if constexpr (S::SMALL_TAIL < 0) {
     // any list length: every group tests four entries (the last one's padding is masked)
