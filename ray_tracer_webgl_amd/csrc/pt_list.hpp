@@ -165,24 +165,32 @@ __device__ __forceinline__ void list_scan(const PtKernelArgs& A, const Path& p, 
   // PHASE 2: exact evaluation of the queued candidates, newest (largest index) first
   const float ya = rcp_newton(a); // per-ray reciprocal for hit_root
   const uint32_t a_guard = hit_root_guard(a);
-  while (pt_ballot(q_cnt != 0u) != 0ull) {
-    if (q_cnt != 0u) {
-      const uint32_t idx = q0 & 0xffffu;
-      q0 = __builtin_amdgcn_alignbit(q1, q0, 16);
-      q1 = __builtin_amdgcn_alignbit(q2, q1, 16);
-      q2 >>= 16;
-      q_cnt--;
-      const float4 g = S::geom_at(A, idx);
-      float half_b, c, disc; sphere_test(o, d, a, g, half_b, c, disc); // bit-identical to the scan's values
-      (void)c;
-      const float v = hit_root(half_b, disc, a, ya, a_guard); // :156-161 (see the note above)
-      const bool in_range = !(v < PT_MIN_T) && (v < closest || (hit < 0 && v <= closest));
-      if (in_range) {
-        closest = v;
-        hit = (int)idx;
-      }
+  // One evaluation: the lane's newest queued candidate (bit-identical re-test, hit_root :156-161, order-free acceptance);
+  // the first one stands in front of the loop (a loop's first trip costs its wave three taken branches, small_scan below).
+#define PT_LIST_EXACT_STEP \
+    if (q_cnt != 0u) { \
+      const uint32_t idx = q0 & 0xffffu; \
+      q0 = __builtin_amdgcn_alignbit(q1, q0, 16); \
+      q1 = __builtin_amdgcn_alignbit(q2, q1, 16); \
+      q2 >>= 16; \
+      q_cnt--; \
+      const float4 g = S::geom_at(A, idx); \
+      float half_b, c, disc; sphere_test(o, d, a, g, half_b, c, disc); \
+      (void)c; \
+      const float v = hit_root(half_b, disc, a, ya, a_guard); \
+      const bool in_range = !(v < PT_MIN_T) && (v < closest || (hit < 0 && v <= closest)); \
+      if (in_range) { \
+        closest = v; \
+        hit = (int)idx; \
+      } \
+    }
+  if (pt_ballot(q_cnt != 0u) != 0ull) {
+    PT_LIST_EXACT_STEP
+    while (pt_ballot(q_cnt != 0u) != 0ull) {
+      PT_LIST_EXACT_STEP
     }
   }
+#undef PT_LIST_EXACT_STEP
   h.closest = closest; h.hit = hit; h.lit_from = lit_from;
 }
 
