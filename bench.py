@@ -89,53 +89,143 @@ def usable_cores():
     return max(1, n)
 
 
-def spawn_ranks(n):
+# Rendezvous and every collective: a rank that never arrives fails the others after 3 min instead of the
+# backends' 10-30 min defaults (the driver's limit for a run is 10 min).  Not tighter: the first `import torch`
+# on a fresh box pages the image in for 1-2 min and the ranks need not finish that together.  The launchers
+# (spawn_ranks below, torch.distributed.run) notice a DEAD rank within seconds; this bound is for a live one that hangs.
+RDZV_TIMEOUT_S = 180
+
+
+def ipc_env():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 for every launch style (self-started ranks, torchrun, a bare
+    rank), set before torch / HIP is loaded.  RCCL shares its xGMI transport buffers between the
+    ranks' processes through HIP IPC handles; this pool's host driver exports device memory as
+    dmabuf only, and with the ROCr runtime's legacy IPC mode (its default) the first communicator
+    fails with `hipIpcGetMemHandle: invalid argument`.  A value the caller exported is kept."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def spawn_ranks(n, job_timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh
-    processes, one per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line, fail if any rank
-    fails.  This parent makes no GPU call and replaces no process."""
+    processes, one per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line, and SUPERVISE them:
+    every child is polled; the first one that ends with a non-zero code (a bad device, an
+    out-of-memory kill, a GPU fault, at start-up or in the middle of a frame) ends the job — the
+    other ranks, which would otherwise sit in the rendezvous or in a collective waiting for it, are
+    terminated (exactly the children started here, each in its own session), and the parent
+    returns that code within seconds with the rank's number and its last stderr lines.  This
+    parent makes no GPU call and replaces no process."""
+    import collections
+    import signal
+    import threading
+
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, tails, out0, readers = [], [], [], []
+
+    def pump(stream, keep, sink):
+        for line in stream:
+            keep.append(line)
+            if sink is not None:
+                sink.write(line)
+                sink.flush()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        if rc != 0:
-            p.terminate()  # exactly the children started above
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            p.wait()
-        rc = rc or p.returncode
-    for line in (out0 or "").splitlines():  # stdout carries the JSON line only (gloo chats on stdout)
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, text=True, start_new_session=True,
+                             stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=subprocess.PIPE)
+        procs.append(p)
+        tails.append(collections.deque(maxlen=12))
+        readers.append(threading.Thread(target=pump, args=(p.stderr, tails[r], sys.stderr), daemon=True))
+        if r == 0:
+            readers.append(threading.Thread(target=pump, args=(p.stdout, out0, None), daemon=True))
+    for t in readers:
+        t.start()
+    print("bench.py: started ranks " + " ".join("%d:pid%d" % (r, p.pid) for r, p in enumerate(procs)), file=sys.stderr, flush=True)
+
+    def stop_all(grace=5.0):
+        """SIGTERM, then SIGKILL, to the sessions of the children started above — nobody else."""
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, sig)  # start_new_session: the child leads its own process group
+                    except (ProcessLookupError, PermissionError):
+                        pass
+            end = time.time() + grace
+            while time.time() < end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+
+    rc, failed = 0, None
+    deadline = time.time() + job_timeout_s if job_timeout_s else None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, rc = bad[0], codes[bad[0]]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline and time.time() > deadline:
+                failed, rc = -1, 124
+                break
+            time.sleep(0.02)
+    finally:
+        stop_all()
+    for t in readers:
+        t.join(timeout=2.0)
+    if failed is not None:
+        if failed < 0:
+            print("bench.py: ranks still running after %d s (--job-timeout); all %d terminated" % (job_timeout_s, n), file=sys.stderr)
+        else:
+            print("bench.py: rank %d (pid %d) ended with code %d; the other %d rank(s) were terminated.  Its last stderr lines:"
+                  % (failed, procs[failed].pid, rc, n - 1), file=sys.stderr)
+            for line in tails[failed]:
+                sys.stderr.write("    [rank %d] %s" % (failed, line))
+        sys.stderr.flush()
+        return rc if rc > 0 else 1  # a signal's negative code is still a failure
+    for line in "".join(out0).splitlines():  # stdout carries the JSON line only (gloo chats on stdout)
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
-    return rc
+    return 0
 
 
 def spawn_selftest(mode):
     """What a rank does under --spawn-selftest: no GPU, no rendering — join the gloo group the
-    parent set up, prove every rank is there, let rank 0 print the line the parent relays."""
+    parent set up, prove every rank is there, let rank 0 print the line the parent relays.  The
+    failing modes rehearse a rank that dies where the others cannot see it: `die-early` before the
+    rendezvous (rank 0 waits in init_process_group), `die-in-collective` after it (rank 0 waits in
+    an all_reduce the dead rank never joins), `fail` after the collectives."""
+    import datetime
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if mode == "die-early" and rank == world - 1:
+        print("selftest: rank %d leaves before the rendezvous" % rank, file=sys.stderr, flush=True)
+        os._exit(5)
     import torch
     import torch.distributed as dist
 
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=RDZV_TIMEOUT_S))
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t)
+    if mode == "die-in-collective":
+        if rank == world - 1:
+            print("selftest: rank %d leaves while the others wait in a collective" % rank, file=sys.stderr, flush=True)
+            os._exit(7)
+        dist.all_reduce(t)  # never completes: the last rank is gone
+    if mode == "hang":  # nobody dies, nobody finishes: only the job's own time limit ends this
+        if rank == world - 1:
+            time.sleep(3600)
+        dist.all_reduce(t)
     if mode == "fail" and rank == world - 1:
         os._exit(3)  # a rank that dies after the rendezvous: the parent must report failure
     if rank == 0:
         print(json.dumps({"selftest": True, "ranks": dist.get_world_size(), "rank_sum": float(t.item()),
-                          "local_rank": int(os.environ["LOCAL_RANK"])}), flush=True)
+                          "local_rank": int(os.environ["LOCAL_RANK"]),
+                          "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
     if mode == "ok":
         dist.barrier()
         dist.destroy_process_group()
@@ -218,12 +308,15 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL code path even with one rank (rehearsal of the collectives on a one-GPU box)")
-    ap.add_argument("--spawn-selftest", default="", choices=["", "ok", "fail"],
+    ap.add_argument("--job-timeout", type=int, default=540,
+                    help="self-started ranks (--gpus N from a bare shell): end the job after this many seconds (0 = never)")
+    ap.add_argument("--spawn-selftest", default="", choices=["", "ok", "fail", "die-early", "die-in-collective", "hang"],
                     help="CPU-only check of the self-launch path: ranks rendezvous over gloo and report (tests/test_dist_cpu.py)")
     args = ap.parse_args()
 
+    ipc_env()  # before torch / HIP is loaded, for every launch style
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args.gpus))  # before anything touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus, args.job_timeout or None))  # before anything touches the GPU
     if args.spawn_selftest:
         raise SystemExit(spawn_selftest(args.spawn_selftest))
     if args.config == "default":
@@ -251,19 +344,22 @@ def main():
     torch.cuda.set_device(local_rank)
     ranks_seen = 1
     if use_dist:
+        import datetime
+
         import torch.distributed as dist
 
+        limit = datetime.timedelta(seconds=RDZV_TIMEOUT_S)
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         with stdout_to_stderr():
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=limit)
             ranks_seen = dist.get_world_size()
             # bring the communicator up here (RCCL initialises lazily, and talks while it does)
             t_up = torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t_up)
+            dist.all_reduce(t_up, async_op=True).wait(timeout=limit)  # a rank that died since the rendezvous: an error here, not a hang
             if args.backend == "nccl":
                 torch.cuda.synchronize()
 

@@ -131,3 +131,80 @@ def test_bench_workload_plan_and_digest_helpers():
     assert bench.frame_digest(torch.from_numpy(a)) == bench.frame_digest(a)
     ap_default = [ln for ln in open(os.path.join(ROOT, "bench.py")) if '"--scaling"' in ln]
     assert ap_default and 'default="strong"' in ap_default[0]
+
+
+def _pids_started(err):
+    import re
+
+    m = re.search(r"started ranks (.*)", err)
+    assert m, err[-2000:]
+    return [int(x) for x in re.findall(r"pid(\d+)", m.group(1))]
+
+
+def _gone(pid):
+    """No such process any more (a zombie cannot be: the parent reaped its children, and it has ended too)."""
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return True
+    except PermissionError:
+        return False
+    try:
+        return open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0] == "Z"
+    except OSError:
+        return True
+
+
+@pytest.mark.parametrize("mode,code", [("die-early", 5), ("die-in-collective", 7)])
+def test_bench_fails_fast_when_a_rank_dies_where_rank0_cannot_see_it(mode, code):
+    """a rank that exits BEFORE the rendezvous (rank 0 sits in init_process_group) or
+    while rank 0 waits for it in a collective must end the whole job in seconds — with its code,
+    its number and its last words — and leave no process behind."""
+    import time
+
+    t0 = time.time()
+    rc, lines, err = _run_bench("--gpus", "3", "--spawn-selftest", mode)
+    took = time.time() - t0
+    assert rc == code, (rc, err[-2000:])
+    assert took < 30.0, "the parent took %.1f s to notice the dead rank" % took
+    assert not lines, "no JSON line from a failed job"
+    assert "rank 2" in err and "ended with code %d" % code in err and "[rank 2] selftest: rank 2 leaves" in err, err[-2000:]
+    pids = _pids_started(err)
+    assert len(pids) == 3
+    deadline = time.time() + 5.0
+    while time.time() < deadline and not all(_gone(p) for p in pids):
+        time.sleep(0.1)
+    assert all(_gone(p) for p in pids), "orphan rank processes: %s" % [p for p in pids if not _gone(p)]
+
+
+def test_bench_job_timeout_ends_ranks_that_never_finish():
+    """A live rank that hangs (here: rank 0 waits in a collective, the dead rank's exit code is 0 so
+    nothing looks failed) is ended by --job-timeout, not by the driver's run limit."""
+    import time
+
+    t0 = time.time()
+    rc, lines, err = _run_bench("--gpus", "2", "--spawn-selftest", "hang", "--job-timeout", "8")
+    assert rc == 124 and time.time() - t0 < 40.0, (rc, err[-2000:])
+    assert all(_gone(p) for p in _pids_started(err))
+
+
+def test_ipc_mode_is_set_for_every_launch_style():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 reaches self-started ranks AND a rank started by a launcher
+    (bench.py sets it in main() before torch is imported; a caller's own value is kept)."""
+    rc, lines, err = _run_bench("--gpus", "2", "--spawn-selftest", "ok")
+    assert rc == 0 and lines[0]["ipc_mode_legacy"] == "0", err[-2000:]
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn-selftest", "ok"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    assert line["ipc_mode_legacy"] == "0"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn-selftest", "ok"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    assert line["ipc_mode_legacy"] == "1"
