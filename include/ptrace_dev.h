@@ -17,8 +17,10 @@ extern "C" {
  * clocks, segments per time bin).  Synchronises the stream.  Returns the number of values written
  * (at most cap), < 0 on error. */
 long pt_debug_counters(pt_ctx* ctx, unsigned long long* out, size_t cap);
-/* Per wave {start, queue dry (0 = never saw it dry), end} of the last counted launch, in 100 MHz
- * ticks.  Returns the number of waves written (at most cap_waves), < 0 when there is no log. */
+/* Per wave FOUR u64 of the last counted launch: {start, queue dry (0 = never saw it dry), end} in 100 MHz
+ * ticks, then where the wave ran: HW_REG_HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+ * | HW_REG_XCC_ID << 32.  `out` holds 4 * cap_waves values.  Returns the number of waves written (at most
+ * cap_waves), < 0 when there is no log. */
 long pt_debug_wave_log(pt_ctx* ctx, unsigned long long* out, size_t cap_waves);
 /* Watchdog for the A/B tools (tools/ab_kernels.py, tools/sweep_knobs.py, ...): waits for everything
  * enqueued on the context's stream WITHOUT blocking in the driver — an event is recorded and polled

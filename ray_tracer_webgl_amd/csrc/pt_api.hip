@@ -897,16 +897,37 @@ static size_t bind_grid(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& A, co
   return 0;
 }
 
+// Workgroups of `block` threads really RESIDENT on a CU at once: the occupancy query (LDS, VGPRs, and an SGPR rule
+// that leaves out the trap handler's 16 per wave) capped by what the kernel is BUILT FOR (pt_kernel_args.h PT_WAVES_*,
+// the kernel's amdgpu_waves_per_eu).  A launch of more workgroups than this is not wrong, but the extra ones start
+// only when others end: for the shared queue that is an empty wave at the end, for a statically dealt launch a share
+// of the frame that begins when everybody else is done (the reference's 25-spp paused frame x 4: 2.98 -> 2.44 ms).
+static hipError_t resident_blocks(const void* kfn, uint32_t block, size_t lds, int built_for, int* out) {
+  int n = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)block, lds);
+  if (e != hipSuccess) return e;
+  const int cap = built_for * 4 / (int)(block / 64u);  // four SIMDs per CU, block / 64 waves per workgroup
+  *out = n < cap ? n : cap;
+  return hipSuccess;
+}
+// what a trace kernel is built for, by how it looks at the list (every build of a path shares its figure; the one twin
+// whose tallies cost it two waves has its own)
+static int built_for_waves(int path, const void* kfn) {
+  if (path == PT_GEOM_SMALL) return PT_WAVES_SMALL;
+  if (path == PT_GEOM_BVH || path == PT_GEOM_GRID) return kfn == pt_extra_kernel(PT_X_GRID_CELLS_COUNT) ? PT_WAVES_TWIN_CELLS : PT_WAVES_WALK;
+  return path == PT_GEOM_LDS ? PT_WAVES_LIST_LDS : PT_WAVES_LIST;
+}
+
 // walk kernels: whichever of 256 / 512 / 1024 threads puts the most waves on a CU (the staged scene is
 // paid once per workgroup, the parked path state and the VGPRs per wave)
-static uint32_t walk_block_threads(const void* kfn, size_t scene, size_t lds_max) {
+static uint32_t walk_block_threads(const void* kfn, int built_for, size_t scene, size_t lds_max) {
   uint32_t block = 0;
   int best_waves = -1;
   for (uint32_t b = 256; b <= 1024; b *= 2) {
     const size_t l = scene + (size_t)PT_PARK_STRIDE * 4 * b;
     if (l > lds_max) continue;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kfn, (int)b, l) != hipSuccess) {
+    if (resident_blocks(kfn, b, l, built_for, &n) != hipSuccess) {
       (void)hipGetLastError(); // a size this kernel cannot run at: not an error of this call
       continue;
     }
@@ -922,7 +943,7 @@ static uint32_t walk_block_threads(const void* kfn, size_t scene, size_t lds_max
   return block ? block : 1024u;
 }
 
-static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L, bool deal_statically = false) {
+static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launch* L) {
   PtKernelArgs& A = L->A;
   {
     int rc = fill_uniforms(c, n_passes, A);
@@ -946,7 +967,7 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     const size_t scene = path == PT_GEOM_BVH ? bind_hierarchy(c, rr, lds_room, A, &kfn) : bind_grid(c, rr, lds_room, A, &kfn);
     A.lds_scene_bytes = (uint32_t)scene;
     A.coop_max_live = 0;  // (the walk kernels have no tail mode: pt_trace_body.hpp)
-    block = walk_block_threads(kfn, scene, lds_max);
+    block = walk_block_threads(kfn, built_for_waves(path, kfn), scene, lds_max);
     lds = scene + (size_t)PT_PARK_STRIDE * 4 * block;
   } else {
     // the LDS copy exists whenever the list fits; the scalar and small-list walks only change how the
@@ -974,8 +995,11 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   }
   A.block_threads = block;
   int per_cu = 0;
-  PT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)block, lds));
+  PT_HIP(c, resident_blocks(kfn, block, lds, built_for_waves(path, kfn), &per_cu));
   if (per_cu < 1) per_cu = 1;
+#ifdef PT_DEV_KNOBS
+  if (const char* e = getenv("PT_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 32) per_cu = v; }
+#endif
 
   // Items a wave reserves per queue atomic.  Items are numbered tile-major, so a reservation is
   // also a run of neighbouring pixels: big reservations keep a wave's lanes on one tile (more
@@ -1016,12 +1040,20 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   // items round-robin to the waves instead (no atomic; the cost-ordered tile list still spreads the
   // heavy tiles over the waves).
   A.n_waves = grid * (block / 64u);
-  // ... and items of one or two samples up to 64 items per lane (16 passes of 1 / 2 spp at the reference's size: 0.65 / 1.14 ms
-  // against 2.89 / 2.89 through the queue, whose head was the limit; with 4-spp items static dealing costs the cover scene
-  // +14 % — its long paths need the queue's balance — so those keep the queue, with reservations sized as above:
-  // 2.96 -> 1.84 ms; tools/queue_shapes.py, profiles/r04_ab_runs.txt)
-  const bool short_items = c->params.samples_per_pixel <= 2 && items < 64ull * (unsigned long long)A.n_waves * 64ull;
-  A.queue_static = (deal_statically || short_items || items < 8ull * (unsigned long long)A.n_waves * 64ull) ? 1u : 0u;
+  // WHEN to deal statically: by the SAMPLES a lane gets, not only by its items.  The queue's balance is worth its atomics once
+  // a lane's share is long enough for the streams' lengths to spread; below that the static deal wins, and the reservations
+  // sized for the queue head (>= 1100 / spp items) would leave most waves of a short launch without any.  Measured on the
+  // reference's scene and size (7 168 waves) and on the cover scene (6 144), static / queue in ms (profiles/r05_ab_runs.txt):
+  //   4 spp x 4 passes  (31 samples per lane) 0.53 / 0.78      8 spp x 4  (63) 0.99 / 1.07      25 spp x 2  (98) 1.48 / 1.47
+  //   25 spp x 4 (196) 2.84 / 2.62     25 spp x 8 (392) 5.48 / 4.64     cover scene 16 spp x 1 (84) 3.50 / 3.92     x 2 (169) 5.72 / 4.68
+  // -> statically below 112 samples per lane (rounds 2-4: below 8 ITEMS per lane whatever their length, which dealt the
+  // paused mode's 25-spp frames statically up to 200 samples per lane: 4 of them 2.84 -> 2.62 ms).  Items of one or two
+  // samples keep round 4's bound of 64 items per lane (16 passes of 1 / 2 spp at the reference's size: 0.59 / 1.08 ms
+  // against 2.89 / 2.89 through the queue, whose head was the limit).
+  const unsigned long long lanes_all = (unsigned long long)A.n_waves * 64ull;
+  const unsigned long long spp_u = (unsigned long long)(c->params.samples_per_pixel > 0 ? c->params.samples_per_pixel : 1);
+  const bool short_items = c->params.samples_per_pixel <= 2 && items < 64ull * lanes_all;
+  A.queue_static = (short_items || items * spp_u < 112ull * lanes_all) ? 1u : 0u;
 #ifdef PT_DEV_KNOBS
   if (const char* e = getenv("PT_QUEUE_STATIC")) A.queue_static = atoi(e) ? 1u : 0u;
   if (const char* e = getenv("PT_COST_FEEDBACK")) A.cost_feedback = atoi(e) ? 1u : 0u;
@@ -1034,11 +1066,19 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     if (c->params.samples_per_pixel < 2) A.cost_feedback = 0u;
     // FEWER WAVES for the shortest launches.  A launch of a lane-step or two per resident lane is all drain: a wave ends when
     // its slowest lane does, and with fewer waves on a SIMD each step is faster and each wave deals more items to its lanes.
-    // One-sample items want ~4.6 per lane, two-sample items ~3.4 (the reference's 1280x702 frame, 1 spp: 0.115 -> 0.081 ms
-    // with 43 % of the resident workgroups; 2 spp: 0.132 -> 0.116 with 58 %; from 4 spp on the full grid wins).  Scheduling only.
+    // One-sample items want ~4.6 per lane, two-sample items ~3.4 — in WHOLE workgroups per CU, so that no CU carries one more
+    // than its neighbours (the reference's 1280x702 frame, 1 spp: three of the seven resident workgroups per CU, 0.115 ->
+    // 0.081 ms; 2 spp: four, 0.132 -> 0.116; from 4 spp on the full grid wins; re-swept in round 5 on the corrected grid:
+    // 3.8 / 4.2 / 4.6 / 5.0 / 5.4 items per lane -> 0.089 / 0.088 / 0.082 / 0.091 / 0.087 ms).  Scheduling only.
     if (c->params.samples_per_pixel <= 2) {
-      const unsigned long long per_wg = (unsigned long long)block * (c->params.samples_per_pixel == 1 ? 46ull : 34ull) / 10ull;
-      const unsigned long long fewer = (items + per_wg - 1) / per_wg;
+      unsigned long long x10 = c->params.samples_per_pixel == 1 ? 46ull : 34ull;
+#ifdef PT_DEV_KNOBS
+      if (const char* e = getenv(c->params.samples_per_pixel == 1 ? "PT_FEWER_X10_1" : "PT_FEWER_X10_2")) { const int v = atoi(e); if (v >= 1) x10 = (unsigned long long)v; }
+#endif
+      const unsigned long long per_wg = (unsigned long long)block * x10 / 10ull;
+      unsigned long long fewer = (items + per_wg - 1) / per_wg;
+      const unsigned long long cus = (unsigned long long)c->num_cus;
+      if (fewer > cus) fewer = (fewer + cus / 2) / cus * cus;  // whole workgroups per CU
       if (fewer >= 1 && fewer < grid) {
         grid = (uint32_t)fewer;
         A.n_waves = grid * (block / 64u);
@@ -1084,13 +1124,13 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   A.wave_log = nullptr;
   if (c->count_work && (path == PT_GEOM_BVH || path == PT_GEOM_GRID || path == PT_GEOM_SMALL)) { // measuring twin: not a product launch, may allocate
     const size_t n_waves = (size_t)grid * (block / 64);
-    if (n_waves * 3 > c->wave_log_cap) {
+    if (n_waves * PT_WAVE_LOG_WORDS > c->wave_log_cap) {
       if (c->d_wave_log) PT_HIP(c, hipFree(c->d_wave_log));
       c->d_wave_log = nullptr; c->wave_log_cap = 0;
-      PT_HIP(c, hipMalloc(&c->d_wave_log, n_waves * 3 * sizeof(unsigned long long)));
-      c->wave_log_cap = n_waves * 3;
+      PT_HIP(c, hipMalloc(&c->d_wave_log, n_waves * PT_WAVE_LOG_WORDS * sizeof(unsigned long long)));
+      c->wave_log_cap = n_waves * PT_WAVE_LOG_WORDS;
     }
-    PT_HIP(c, hipMemsetAsync(c->d_wave_log, 0, n_waves * 3 * sizeof(unsigned long long), c->stream));
+    PT_HIP(c, hipMemsetAsync(c->d_wave_log, 0, n_waves * PT_WAVE_LOG_WORDS * sizeof(unsigned long long), c->stream));
     c->wave_log_n = n_waves;
     A.wave_log = c->d_wave_log;
   }
@@ -1185,10 +1225,11 @@ int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_rende
   memset(static_cast<void*>(F), 0, sizeof *F);  // (padding too: plans are compared bytewise)
   // frames k .. k + n - 1 are the passes 0 .. n - 1 of ONE launch: pass p renders at u_time = time + float(first_pass + p + k) *
   // time_step (pt_refill.hpp), which IS frame k + p's time, into slab p
-  // (a GROUP of frames is still a short launch of uniform items: dealt statically whatever its size, since the shared
-  // queue's atomics would cost more than the frames — 8 frames of the reference's size: 0.37 ms per frame with them; a single
-  // frame keeps the rule of every launch: statically below eight items per lane)
-  int rc = prepare_launch(c, n_frames, false, &F->L, n_frames > 1u);
+  // (a group of frames is dealt like any other launch of its shape — prepare_launch: statically for one- and two-sample
+  // items, as the reference's frames are, through the shared queue from there on.  Round 4 dealt every group statically
+  // "whatever its size"; measured in round 5 on the reference's scene and size: groups of 4- / 8- / 25-sample frames 0.126 /
+  // 0.238 / 0.727 ms per frame dealt statically, 0.126 / 0.211 / 0.561 through the queue; profiles/r05_ab_runs.txt)
+  int rc = prepare_launch(c, n_frames, false, &F->L);
   if (rc != PT_OK) return rc;
   F->L.A.frame_ctr = ctr;
   F->L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
@@ -1401,12 +1442,13 @@ PT_API long pt_debug_counters(pt_ctx* c, unsigned long long* out, size_t cap) {
 }
 
 // Dev diagnostics of the measuring twins: per wave {start, queue dry (0 = never saw it dry), end}
-// of the last counted launch, in 100 MHz ticks.  Returns the number of waves, or < 0.
+// of the last counted launch, in 100 MHz ticks, and where it ran (HW_ID | XCC_ID << 32): four u64 per wave.
+// Returns the number of waves, or < 0.
 PT_API long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_waves) {
   if (!c || !c->d_wave_log || !out) return -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
   const size_t n = c->wave_log_n < cap_waves ? c->wave_log_n : cap_waves;
-  if (hipMemcpy(out, c->d_wave_log, n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  if (hipMemcpy(out, c->d_wave_log, n * PT_WAVE_LOG_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
   return (long)n;
 }
 

@@ -72,7 +72,7 @@ struct PtKernelArgs {
   float grid_r2_near;              // rays with |o - c0|^2 <= this ((0.9999 d_near - s0)^2) walk the cells
   float grid_lo_n[3], grid_hi_n[3];  // [lo, hi] widened by 1e-6 d_near: the entry slab test of those rays
   uint32_t lds_scene_bytes;        // dynamic LDS taken by the staged scene; the parked path state follows
-  unsigned long long* wave_log;    // COUNT twins only (NULL otherwise): per wave {start, queue dry, end} in 100 MHz ticks
+  unsigned long long* wave_log;    // COUNT twins only (NULL otherwise): per wave PT_WAVE_LOG_WORDS x u64 {start, queue dry, end in 100 MHz ticks; HW_ID | XCC_ID << 32}
   uint32_t refill_min;             // lanes that must be waiting for an item before a busy wave runs the refill code
   uint32_t carry_lanes;            // the walk moves on when fewer lanes than this (and less than half) still walk
   float bvh_kinv;                  // boxes are stored in the frame (x - c0) / kinv
@@ -92,6 +92,29 @@ struct PtKernelArgs {
                                    // hipGraph advance it on the device); points at a zero cell otherwise.  Never NULL.
 };
 
+// ---- waves per SIMD each trace kernel is BUILT FOR -------------------------------------------------------------
+// Every trace kernel carries amdgpu_waves_per_eu(N, N): the compiler keeps it inside the VGPR and SGPR budget of N
+// waves per SIMD, and its SGPR budget counts the 16 SGPRs per wave this platform's trap handler takes
+// (800 / N - 16, rounded down to the allocation granule of 16; AMDGPUBaseInfo getMaxNumSGPRs).  The HIP occupancy
+// query does NOT count them: for a kernel of 106 SGPRs it answers 800 / 112 = 7 waves, the SIMD holds
+// 800 / (112 + 16) = 6.  Rounds 1-4 launched "7 workgroups of 256 threads per CU" for the list and small-list
+// kernels on that answer; the wave log (round 5: HW_ID per wave, profiles/r05_residency.txt) shows wave slots
+// 0-5 in use on every SIMD and the seventh workgroup of each CU starting only when another one has ended.  The host
+// therefore takes min(occupancy query, N) — pt_api.hip resident_blocks() — with N from this table.
+#ifndef PT_WAVES_WALK
+#define PT_WAVES_WALK 6       // hierarchy and grid walks: latency-bound, 80 VGPRs (pt_kernels.hip)
+#endif
+#ifndef PT_WAVES_LIST
+#define PT_WAVES_LIST 7       // scalar-load list walks: 94 SGPRs with 8-16 of them spilled, 58-61 VGPRs (config 4 through it -2.4 %, the
+#endif                        // reference's scene -2.0 %, config 2 -0.4 % against six; profiles/r05_ab_runs.txt)
+#define PT_WAVES_LIST_LDS 6   // the LDS list walk: 79 VGPRs (at seven it spills vector registers)
+#ifndef PT_WAVES_SMALL
+#define PT_WAVES_SMALL 7      // small-list kernels: 94 SGPRs (+16 = 112: seven really fit), 59 VGPRs
+#endif
+#define PT_WAVES_TWIN_CELLS 4 // the measuring twin of the cells-only grid kernel (98 VGPRs with its tallies live)
+#define PT_BUILT_FOR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+enum { PT_WAVE_LOG_WORDS = 4 };  // u64 per wave in PtKernelArgs.wave_log
 enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);

@@ -36,17 +36,17 @@
 
 // blockDim.x is a multiple of 64 (256 normally, 1024 when the staged list is large and only one
 // workgroup fits per CU); dynamic LDS = PT_LDS_ENTRIES(n_spheres) * 16 bytes.
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_LIST_LDS) void pt_trace_kernel(const PtKernelArgs A) {
   pt_trace_body<true, true>(A);
 }
 
 // the scalar-load walk (PT_GEOM_SCALAR) with the LDS copy kept for the per-lane gathers
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_LIST) void pt_trace_kernel_scalar(const PtKernelArgs A) {
   pt_trace_body<false, true>(A);
 }
 
 // lists beyond the LDS (10 232 < n <= 65 528): scalar-load walk, gathers from global memory
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_LIST) void pt_trace_kernel_scalar_nolds(const PtKernelArgs A) {
   pt_trace_body<false, false>(A);
 }
 
@@ -54,29 +54,27 @@ extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds(
 // leaves room for them, six waves per SIMD (80 VGPRs) beat five with no spills (config 2: -5 %).
 // The kernels for larger scenes are held to four waves by their LDS footprint and keep their
 // registers.
-#ifndef PT_BVH_WAVES
-#define PT_BVH_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
-#endif
+// (PT_BUILT_FOR / PT_WAVES_*: pt_kernel_args.h — what a kernel is built for is what the host launches)
 // the hierarchy walk (PT_GEOM_BVH): nodes + slots staged in LDS (dynamic LDS =
 // PT_BVH_LDS_BYTES32(n_nodes, n_slots) + parking), or read from global memory / L2 when they do not fit
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh(const PtKernelArgs A) {
   pt_trace_body<false, false, 1>(A);
 }
 // nodes staged (dynamic LDS = (n_nodes + 1) * 16 bytes + parking), slots read from global memory
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_nodes(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh_nodes(const PtKernelArgs A) {
   pt_trace_body<false, false, 2>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh_gmem(const PtKernelArgs A) {
   pt_trace_body<false, false, 3>(A);
 }
 // the grid walk (PT_GEOM_GRID): cells + entries staged in LDS, cells only, or nothing
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid(const PtKernelArgs A) {
   pt_trace_body<false, false, 4>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_cells(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid_cells(const PtKernelArgs A) {
   pt_trace_body<false, false, 5>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid_gmem(const PtKernelArgs A) {
   pt_trace_body<false, false, 6>(A);
 }
 // --------------------------------------------------------------------------------------------

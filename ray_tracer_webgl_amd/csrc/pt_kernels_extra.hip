@@ -9,56 +9,56 @@
 #include "pt_extra.h"
 
 // measuring twins (PT_OPT_COUNT_WORK): the same walks with the executed-work tallies
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh_count(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh_count(const PtKernelArgs A) {
   pt_trace_body<false, false, 1, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_count(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid_count(const PtKernelArgs A) {
   pt_trace_body<false, false, 4, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_cells_count(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_TWIN_CELLS) void pt_trace_kernel_grid_cells_count(const PtKernelArgs A) {
   pt_trace_body<false, false, 5, true>(A);
 }
 // (the small-list kernel's twin: the phase clock of config 4 and State::default)
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_count(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_count(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, true>(A);
 }
 
 // Russian-roulette builds (PT_OPT_RUSSIAN_ROULETTE, opt-in; same launch shapes as their namesakes)
 // (the small-list kernel: one build per list length modulo four, like pt_kernels_small.hip)
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t0_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t0_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, true, 0>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t1_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t1_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, true, 1>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t2_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t2_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, true, 2>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t3_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t3_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, true, 3>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_LIST) void pt_trace_kernel_scalar_rr(const PtKernelArgs A) {
   pt_trace_body<false, true, 0, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_scalar_nolds_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_LIST) void pt_trace_kernel_scalar_nolds_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 0, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_bvh_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 1, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_nodes_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh_nodes_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 2, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_bvh_gmem_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_bvh_gmem_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 3, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 4, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) PT_BVH_WAVES void pt_trace_kernel_grid_cells_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid_cells_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 5, false, true>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_grid_gmem_rr(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_WALK) void pt_trace_kernel_grid_gmem_rr(const PtKernelArgs A) {
   pt_trace_body<false, false, 6, false, true>(A);
 }
 

@@ -12,16 +12,16 @@
 #include "pt_trace_body.hpp"
 #include "pt_extra.h"
 
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t0(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t0(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, false, 0>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t1(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t1(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, false, 1>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t2(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t2(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, false, 2>(A);
 }
-extern "C" __global__ __launch_bounds__(1024) void pt_trace_kernel_small_t3(const PtKernelArgs A) {
+extern "C" __global__ __launch_bounds__(1024) PT_BUILT_FOR(PT_WAVES_SMALL) void pt_trace_kernel_small_t3(const PtKernelArgs A) {
   pt_trace_body<false, true, 7, false, false, 3>(A);
 }
 

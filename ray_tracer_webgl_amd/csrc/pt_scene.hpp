@@ -238,6 +238,7 @@ __device__ __forceinline__ void park_load(const PtKernelArgs& A, Path& p) {
 template <bool COUNT>
 struct Tally {
   unsigned long long t_wave_start = 0, t_wave_dry = 0;
+  uint32_t hw_id = 0, xcc_id = 0;  // where the wave runs: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID, read once at its start
   uint32_t tb_bin = 0xffffffffu, tb_acc = 0;
   uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
            n_carried = 0;
@@ -252,6 +253,9 @@ struct Tally {
     if constexpr (COUNT) {
       t_wave_start = __builtin_amdgcn_s_memrealtime();
       ph_mark = __builtin_amdgcn_s_memtime();
+      // s_getreg_b32 hwreg(HW_REG_HW_ID) [31:0] and hwreg(HW_REG_XCC_ID) [3:0]; simm16 = (size - 1) << 11 | offset << 6 | id
+      hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);
     }
   }
   __device__ __forceinline__ void walk(unsigned long long mask) { if constexpr (COUNT) { n_walk_it++; n_walk_ln += (uint32_t)__popcll(mask); } }
@@ -313,8 +317,9 @@ struct Tally {
         if (tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
         for (int k = 0; k < PT_N_PHASES; k++) atomicAdd(&A.counters[PT_CTR_PHASES + k], ph_t[k]);
         if (A.wave_log) {
-          unsigned long long* wl = A.wave_log + 3ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+          unsigned long long* wl = A.wave_log + (unsigned long long)PT_WAVE_LOG_WORDS * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
           wl[0] = t_wave_start; wl[1] = t_wave_dry; wl[2] = __builtin_amdgcn_s_memrealtime();
+          wl[3] = (unsigned long long)hw_id | ((unsigned long long)xcc_id << 32);
         }
       }
     }

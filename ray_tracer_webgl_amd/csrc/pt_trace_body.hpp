@@ -110,8 +110,3 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
   if (lane_id() == 0) atomicAdd(&A.counters[PT_CTR_SEGMENTS], (unsigned long long)seg_count);
   tally.flush(A);
 }
-
-// the walk kernels are built for six waves per SIMD (80 VGPRs): see pt_kernels.hip
-#ifndef PT_BVH_WAVES
-#define PT_BVH_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
-#endif

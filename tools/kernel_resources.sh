@@ -1,14 +1,15 @@
 #!/bin/bash
 # Compact per-kernel resource table (VGPRs, SGPRs, spills, scratch, waves/SIMD) + static instruction
-# counts of the kernels, from a cross-compile of both device translation units (pt_kernels.hip: what every
-# context uses; pt_kernels_extra.hip: Russian-roulette builds, measuring twins) for gfx950 (no GPU needed).
+# counts of the kernels, from a cross-compile of the three device translation units (pt_kernels.hip: what every
+# context uses; pt_kernels_small.hip: the small-list kernels; pt_kernels_extra.hip: Russian-roulette builds, measuring
+# twins) for gfx950 (no GPU needed).
 # Usage: tools/kernel_resources.sh [outdir]   (default /tmp/ptres)
 set -e
 OUT=${1:-/tmp/ptres}
 mkdir -p "$OUT"
 cd "$(dirname "$(readlink -f "$0")")/../ray_tracer_webgl_amd/csrc"
 : > "$OUT/remarks.txt"
-for TU in pt_kernels pt_kernels_extra; do
+for TU in pt_kernels pt_kernels_small pt_kernels_extra; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize \
     -fvisibility=hidden -Wall -Wno-unused-function $PT_EXTRA_FLAGS -Rpass-analysis=kernel-resource-usage \
     -save-temps=obj -c $TU.hip -o "$OUT/$TU.o" 2>> "$OUT/remarks.txt" || { cat "$OUT/remarks.txt"; exit 1; }

@@ -41,11 +41,11 @@ pt.reset()
 pt.set_count_work(True)
 pt.render_passes(passes)
 st = pt.stats()
-buf = np.zeros((20000, 3), np.uint64)
+buf = np.zeros((20000, 4), np.uint64)
 pt.lib.pt_debug_wave_log.restype = C.c_long
 pt.lib.pt_debug_wave_log.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 k = pt.lib.pt_debug_wave_log(pt._ctx, buf.ctypes.data_as(C.c_void_p), len(buf))
-w = buf[:k].astype(np.float64) * 1e-5  # ms
+w = buf[:k, :3].astype(np.float64) * 1e-5  # ms
 t0 = w[:, 0].min()
 start, dry, end = w[:, 0] - t0, np.where(w[:, 1] > 0, w[:, 1] - t0, np.nan), w[:, 2] - t0
 T = end.max()
@@ -53,6 +53,37 @@ print("%d waves, kernel %.2f ms (events %.2f ms); starts within %.3f ms; queue d
       % (k, T, st.render_kernel_ms, start.max(), np.nanmin(dry), np.nanmedian(dry)))
 for q in (0.5, 1.0, 1.5, 2.0, 3.0, 4.0):
     print("  waves still running %.1f ms before the end: %5d of %d" % (q, int((end > T - q).sum()), k))
+# ---- residency: which of the launched waves were on the machine from the start, and where (HW_ID | XCC_ID << 32) ----
+hw = buf[:k, 3]
+slot, simd, cu = (hw & np.uint64(15)).astype(int), ((hw >> np.uint64(4)) & np.uint64(3)).astype(int), ((hw >> np.uint64(8)) & np.uint64(15)).astype(int)
+sh, se, xcc = ((hw >> np.uint64(12)) & np.uint64(1)).astype(int), ((hw >> np.uint64(13)) & np.uint64(7)).astype(int), ((hw >> np.uint64(32)) & np.uint64(15)).astype(int)
+first_end = end.min()
+late = start > 0.05
+print("  residency: %d of %d waves start within 0.05 ms; %d start later, %d of them after the first wave has ENDED (%.3f ms)"
+      % (int((~late).sum()), k, int(late.sum()), int((start > first_end).sum()), first_end))
+edges = [0.0, 0.05, 0.25 * T, 0.5 * T, 0.75 * T, 0.9 * T, 0.95 * T, T + 1e-9]
+hist, _ = np.histogram(start, bins=edges)
+print("  start-time histogram (ms): " + ", ".join("[%.2f, %.2f) %d" % (edges[i], edges[i + 1], hist[i]) for i in range(len(hist))))
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+simd_key = cu_key * 4 + simd
+res_cu = np.bincount(cu_key[~late], minlength=1)
+res_simd = np.bincount(simd_key[~late], minlength=1)
+cus = np.unique(cu_key)
+print("  at t = 0: %d distinct CUs over %d XCCs hold waves; waves per CU: %s; waves per SIMD: %s"
+      % (int((res_cu > 0).sum()), len(np.unique(xcc[~late])),
+         dict(zip(*[x.tolist() for x in np.unique(res_cu[res_cu > 0], return_counts=True)])),
+         dict(zip(*[x.tolist() for x in np.unique(res_simd[res_simd > 0], return_counts=True)]))))
+print("  distinct (XCC, SE, SH, CU, SIMD, slot) at t = 0: %d (= waves really resident; launched %d); wave slots in use: %s"
+      % (len(np.unique(simd_key[~late] * 16 + slot[~late])), k, sorted(np.unique(slot[~late]).tolist())))
+per_xcc = {int(x): int(((xcc == x) & ~late).sum()) for x in np.unique(xcc)}
+per_se = {"%d.%d" % (x, s_): int(((xcc == x) & (se == s_) & ~late).sum()) for x in np.unique(xcc)[:2] for s_ in np.unique(se)}
+print("  resident waves per XCC: %s; per (XCC.SE) of the first two XCCs: %s; CUs per (XCC.SE): %s"
+      % (per_xcc, per_se, {"%d.%d" % (x, s_): len(np.unique(cu_key[(xcc == x) & (se == s_)])) for x in np.unique(xcc)[:2] for s_ in np.unique(se)}))
+if late.any():
+    wg = np.arange(k) // (8 if path == abi.PT_GEOM_GRID else 4)  # waves per workgroup: 512-thread walk kernels, 256-thread small-list ones
+    print("  late waves: workgroup numbers %d ... %d (of %d); they start at %.3f ... %.3f ms; late waves per CU: %s"
+          % (wg[late].min(), wg[late].max(), wg.max() + 1, start[late].min(), start[late].max(),
+             dict(zip(*[x.tolist() for x in np.unique(np.bincount(cu_key[late])[np.bincount(cu_key[late]) > 0], return_counts=True)]))))
 print("  wave end times: median %.2f, 90 %% %.2f, 99 %% %.2f, max %.2f" % (np.median(end), np.quantile(end, 0.9), np.quantile(end, 0.99), T))
 lost = (T - end).sum() / (T * k)
 print("  wave-time lost to the drain (sum of (T - end) / (T x waves)): %.3f" % lost)
