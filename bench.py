@@ -303,6 +303,8 @@ def main():
     ap.add_argument("--cpu-strip", type=int, default=None,
                     help="width of the CPU baseline's column strip (default per config: 10-30 s of CPU work)")
     ap.add_argument("--frames", type=int, default=400, help="--config default: frames per timed replay series")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="--config default: only the replayed animation loop (no host-issued ticks, no paused 25-spp frames): what profiles/collect.sh runs under the PMC passes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 path on a one-GPU box (not a benchmark)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -621,40 +623,8 @@ def main():
 
         # a prior rocprofv3 PMC profile of the same kernel, config and launch shape, if one is committed
         # (profiles/pmc_traffic.json: one record per kernel + config, written by profiles/summarize.py)
-        prior = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof) and world == 1:
-            try:
-                doc = json.load(open(prof))
-                for rec in (doc.get("records") or [doc]):
-                    if (rec.get("kernel") == kernel_name and str(rec.get("config", "2")) == args.config and
-                            rec.get("spp_per_pass") == args.spp_per_pass and rec.get("passes_per_launch") == ppl):
-                        prior = rec
-            except Exception:
-                prior = None
-        counters = None
-        if prior:
-            # counter-derived figures of that PRIOR profile (profiles/summarize.py wrote them from the PMC passes):
-            #   valu_issue_frac  = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
-            #   lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
-            #   fp32_flop_frac   = (2 FMA + MUL) x 64 x lane_utilisation / kernel time / peak
-            lu = None
-            if prior.get("sq_thread_cycles_valu") and prior.get("sq_active_inst_valu"):
-                lu = prior["sq_thread_cycles_valu"] / (64.0 * prior["sq_active_inst_valu"])
-            ff32 = None
-            if lu and prior.get("kernel_ms") and prior.get("sq_insts_valu_fma_f32") is not None:
-                flop = (2.0 * prior["sq_insts_valu_fma_f32"] + prior.get("sq_insts_valu_mul_f32", 0.0)) * 64.0 * lu
-                ff32 = flop / (prior["kernel_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS
-            counters = {
-                "source": "PRIOR profile %s (rocprofv3 --pmc, same kernel and launch shape; not this run)" % prior.get("profile", "profiles/pmc_traffic.json"),
-                "kernel_ms": prior.get("kernel_ms"),
-                "valu_issue_frac": round(prior["valu_issue_frac"], 4) if prior.get("valu_issue_frac") else None,
-                "cycles_per_valu_per_simd": round(2.0 / prior["valu_issue_frac"], 3) if prior.get("valu_issue_frac") else None,
-                "lane_utilisation": round(lu, 4) if lu else None,
-                "fp32_flop_frac": round(ff32, 4) if ff32 else None,
-                "salu_per_valu": round(prior["sq_insts_salu"] / prior["valu_insts_per_launch"], 3) if prior.get("sq_insts_salu") and prior.get("valu_insts_per_launch") else None,
-                "lds_bank_conflict_frac": round(prior["sq_lds_bank_conflict"] / prior["sq_lds_idx_active"], 4) if prior.get("sq_lds_idx_active") else None,
-            }
+        prior = prior_pmc_record(kernel_name, args.config, args.spp_per_pass, ppl) if world == 1 else None
+        counters = counters_of(prior)
         roofline = {
             "kernel": kernel_name,
             "geometry_path": abi.GEOM_NAMES.get(st.geometry_path, "?") + (" (autotuned)" if st.geometry_tuned else ""),
@@ -798,6 +768,46 @@ def main():
         dist.destroy_process_group()
 
 
+def prior_pmc_record(kernel, config, spp_per_pass, passes_per_launch):
+    """The committed rocprofv3 PMC record of this kernel, config and launch shape (profiles/pmc_traffic.json), or None."""
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        doc = json.load(open(prof))
+    except Exception:
+        return None
+    for rec in (doc.get("records") or [doc]):
+        if (rec.get("kernel") == kernel and str(rec.get("config", "2")) == str(config) and
+                rec.get("spp_per_pass") == spp_per_pass and rec.get("passes_per_launch") == passes_per_launch):
+            return rec
+    return None
+
+
+def counters_of(prior):
+    """Counter-derived figures of a PRIOR profile record (profiles/summarize.py wrote it from the PMC passes):
+         valu_issue_frac  = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+         lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+         fp32_flop_frac   = (2 FMA + MUL) x 64 x lane_utilisation / kernel time / peak"""
+    if not prior:
+        return None
+    lu = None
+    if prior.get("sq_thread_cycles_valu") and prior.get("sq_active_inst_valu"):
+        lu = prior["sq_thread_cycles_valu"] / (64.0 * prior["sq_active_inst_valu"])
+    ff32 = None
+    if lu and prior.get("kernel_ms") and prior.get("sq_insts_valu_fma_f32") is not None:
+        flop = (2.0 * prior["sq_insts_valu_fma_f32"] + prior.get("sq_insts_valu_mul_f32", 0.0)) * 64.0 * lu
+        ff32 = flop / (prior["kernel_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS
+    return {
+        "source": "PRIOR profile %s (rocprofv3 --pmc, same kernel and launch shape; not this run)" % prior.get("profile", "profiles/pmc_traffic.json"),
+        "kernel_ms": prior.get("kernel_ms"),
+        "valu_issue_frac": round(prior["valu_issue_frac"], 4) if prior.get("valu_issue_frac") else None,
+        "cycles_per_valu_per_simd": round(2.0 / prior["valu_issue_frac"], 3) if prior.get("valu_issue_frac") else None,
+        "lane_utilisation": round(lu, 4) if lu else None,
+        "fp32_flop_frac": round(ff32, 4) if ff32 else None,
+        "salu_per_valu": round(prior["sq_insts_salu"] / prior["valu_insts_per_launch"], 3) if prior.get("sq_insts_salu") and prior.get("valu_insts_per_launch") else None,
+        "lds_bank_conflict_frac": round(prior["sq_lds_bank_conflict"] / prior["sq_lds_idx_active"], 4) if prior.get("sq_lds_idx_active") else None,
+    }
+
+
 def frame_loop_bench(args):
     """--config default: the reference at its OWN operating point.  State::default (9 spheres, at most
     15 by static/shader.frag:103), 1280x702 (images/14.png; MAX_CANVAS_SIZE 1280, src/dom.rs:13),
@@ -805,12 +815,104 @@ def frame_loop_bench(args):
     shader's render() rule (src/state.rs:127-135, src/lib.rs:65-104, src/webgl.rs:180-205) —
     app.FrameLoop's "reference" mode, with the per-frame work (trace + fold + blend) replayed from
     hipGraphs.  A step is one frame; `value` is frames per second, with Mray/s beside it; the
-    25-spp paused mode (src/webgl.rs:342-346) is timed beside it."""
+    25-spp paused mode (src/webgl.rs:342-346) is timed beside it.  Like the main line it carries
+    `roofline` (the trace launch of one group of 16 frames: pt_trace_kernel_small_t1, a LIST kernel, so
+    executed work = algorithmic work) and `cpu_baseline` (the oracle replaying the same ticks: one
+    1-spp pass + the shader's blend per tick, on this host's cores)."""
     from ray_tracer_webgl_amd.app import frame_loop_benchmark
 
-    out = frame_loop_benchmark(args.frames, args.warmup)
+    out = frame_loop_benchmark(args.frames, args.warmup, extra_legs=not args.no_extra_legs)
+    g = out["group_trace_kernel"]
+    t_launch = g["avg_launch_ms"] * 1e-3
+    # a list kernel tests every sphere for every segment (static/shader.frag:175-196): 20 FLOP each, + ~150 per segment of scatter / RNG / camera
+    flop = g["segments_per_launch"] * (FLOP_PER_SPHERE_TEST * g["n_spheres"] + FLOP_PER_SEGMENT_SHADE)
+    achieved = flop / t_launch / 1e12 if t_launch > 0 else None
+    prior = prior_pmc_record(g["kernel"], "default", g["spp_per_pass"], g["passes_per_launch"])
+    n_pix, k = g["pixels"], g["passes_per_launch"]
+    # HBM bytes of ONE GROUP of frames as built: the trace kernel stores one 16-B slab entry per (pixel, frame); the blend kernel
+    # reads them, reads the previous RGBA8 texture and writes the last two frames' textures and the canvas (src/webgl.rs:186-204)
+    group_bytes = {"trace_slab_stores": 16 * n_pix * k, "blend_slab_loads": 16 * n_pix * k, "blend_rgba8_textures": 4 * n_pix * 4}
+    group_ms = out["animation"]["device_ms_per_frame"] * k if out["animation"].get("device_ms_per_frame") else None
+    out["roofline"] = {
+        "kernel": g["kernel"],
+        "geometry_path": "small (the whole list from SGPRs; lists of <= 16 spheres)",
+        "bound": "valu",
+        "achieved": round(achieved, 3) if achieved else None,
+        "peak": FP32_VALU_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4) if achieved else None,
+        "frac_is": "algorithmic = executed for a list kernel: segments x (20 FLOP x %d spheres + %d scatter / RNG / camera) per launch / "
+                   "the launch's duration (HIP events on the launch stream around the kernel alone, %d launches of the group's own shape "
+                   "through pt_render_passes after the timed region)" % (g["n_spheres"], FLOP_PER_SEGMENT_SHADE, g["launches"]),
+        "avg_launch_ms": g["avg_launch_ms"],
+        "launches": g["launches"],
+        "passes_per_launch": k,
+        "spp_per_pass": g["spp_per_pass"],
+        "segments_per_launch": g["segments_per_launch"],
+        "gray_s_of_the_kernel": round(g["segments_per_launch"] / t_launch / 1e9, 2) if t_launch > 0 else None,
+        "traffic": prior.get("pt_trace_kernel_hbm_bytes_per_launch") if prior else None,
+        "traffic_source": ("PRIOR profile %s (rocprofv3 --pmc WRITE_SIZE + 2*FETCH_SIZE of the group's trace launch)" % prior.get("profile")) if prior else None,
+        "counters": counters_of(prior),
+        "hbm": {
+            "algorithmic_bytes_per_group": group_bytes,
+            "achieved": round(sum(group_bytes.values()) / (group_ms * 1e-3) / 1e9, 1) if group_ms else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(sum(group_bytes.values()) / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if group_ms else None,
+            "note": "all three kernels of a group (trace, blend, advance) over the group's device time: the loop is not HBM-bound either",
+        },
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = frame_loop_cpu_baseline(out)
+        if out["cpu_baseline"] and out["cpu_baseline"]["value"]:
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
     return 0
+
+
+def frame_loop_cpu_baseline(line, budget_s=12.0, min_frames=24):
+    """The CPU oracle replaying the animation loop's ticks as the reference issues them (src/lib.rs:65-104): per tick one 1-spp
+    pass of State::default at u_time = now, then the shader's render() blend with the previous RGBA8 texture
+    (static/shader.frag:387-404) — oracle.render + oracle.blend_rgba8, the checker's own functions, pthread workers over rows on
+    this host's usable cores.  Bounded: whole frames until `budget_s` seconds have passed."""
+    import numpy as np
+
+    cores = usable_cores()
+    flags, native = build_native_oracle()
+    from oracle import oracle
+    from ray_tracer_webgl_amd.state import State
+
+    w, h = 1280, 702
+    st = State(w, h)
+    st.set_flags(is_paused=False)
+    spheres = st.spheres()
+    tex = [np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 4), np.uint8)]
+    now0, dt = 3000.0, 16.7
+    frames, seg_total = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        now = now0 + dt * frames
+        st.update_position(now if frames == 0 else dt)
+        st.update_render_globals()
+        v, p = st.view(), st.to_params(now)
+        acc, seg = oracle.render(spheres, p, 1, nthreads=cores)
+        tex[v.even_odd_count % 2] = oracle.blend_rgba8(acc, p.samples_per_pixel, p, tex[(v.even_odd_count + 1) % 2])
+        frames += 1
+        seg_total += seg
+        if frames >= min_frames and time.perf_counter() - t0 >= budget_s:
+            break
+    t1 = time.perf_counter()
+    st.close()
+    return {
+        "value": round(frames / (t1 - t0), 2),
+        "unit": "frames/s",
+        "mray_s": round(seg_total / (t1 - t0) / 1e6, 2),
+        "cores": cores,
+        "kind": "port",
+        "algorithm": "the oracle's frame loop: one 1-spp pass (linear list walk, scalar code, pthread workers over rows) + the shader's RGBA8 blend per tick",
+        "build": flags,
+        "native_build": native,
+        "sample": "%d whole 1280x702 frames of the same loop (%d segments, %.1f s)" % (frames, seg_total, t1 - t0),
+    }
 
 
 def build_native_oracle():

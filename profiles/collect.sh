@@ -7,6 +7,10 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# round 5: the classes of the VALU stream beside FMA / MUL / TRANS (what are the other two thirds?).  gfx950 exposes
+# SQ_INSTS_VALU_ADD_F32, _FMA_F32, _MUL_F32, _TRANS_F32, _INT32, _CVT and the MFMA families; a name the box does not
+# know fails only its own pass (see pmc6.log).
+PT_PMC_CLASSES=${PT_PMC_CLASSES:-SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_ADD_F16 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_SALU}
 if [ "${PT_COLLECT_MAIN:-1}" = "1" ]; then
 BENCH="python3 bench.py --no-cpu-baseline --no-work-count"   # the default workload (config 2, 16 steps = 1024 spp); keeps the list-walk leg: the scalar list kernel is in the same trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
@@ -20,7 +24,8 @@ for grp in \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32" \
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" \
   "GRBM_GUI_ACTIVE FETCH_SIZE" \
-  "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ; do
+  "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+  "$PT_PMC_CLASSES" ; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1
 done
@@ -29,10 +34,13 @@ cat $OUT/summary.txt
 fi  # PT_COLLECT_MAIN=0 skips the config-2 part (PT_COLLECT_CONFIGS="4" re-collects one config)
 # the other BASELINE configs through the same bench line, each with its own kernel trace and PMC passes: the records
 # bench.py attaches to `--config 3 / 4 / 5` lines (profiles/summarize.py --merge <dirs> writes profiles/pmc_traffic.json)
-for CFG in ${PT_COLLECT_CONFIGS:-3 4 5}; do
+for CFG in ${PT_COLLECT_CONFIGS:-3 4 5 default}; do
   OC=gpurun_out/prof_${TAG}_c$CFG
   mkdir -p $OC
   BC="python3 bench.py --config $CFG --no-cpu-baseline --no-work-count --no-list-walk --no-first-frame"
+  # the reference's own operating point: only the replayed animation loop + the group's trace launch on its own
+  # (the longest pt_trace_kernel_small_t1 dispatches are then the groups of 16 frames, which summarize.py keeps)
+  if [ "$CFG" = "default" ]; then BC="python3 bench.py --config default --no-cpu-baseline --no-extra-legs --frames 400"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OC/kt -- $BC > $OC/kt.log 2>&1
   i=0
   for grp in \

@@ -141,7 +141,9 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
         rec["valu_insts_per_launch"] = pm["SQ_INSTS_VALU"]
         rec["kernel_cycles"] = cycles
         rec["valu_issue_frac"] = 2.0 * pm["SQ_INSTS_VALU"] / (1024.0 * cycles)
-        for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_LDS_BANK_CONFLICT",
+        for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_INT32",
+                  "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_ADD_F16", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_FMA_F64",
+                  "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_LDS_BANK_CONFLICT",
                   "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES",
                   "SQ_INSTS_VMEM_RD", "TCC_HIT_sum", "TCC_MISS_sum"):
             if k in pm:

@@ -106,7 +106,7 @@ class FrameLoop:
         return n
 
 
-def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device=0):
+def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device=0, extra_legs=True):
     """bench.py --config default: the reference at its own operating point (State::default, 9 spheres,
     1280x702 = images/14.png, depth 8; src/state.rs:127-135).  Times (i) the animation loop — 1 spp per
     tick, blended into the RGBA8 textures, replayed from hipGraphs in groups of 16 — and (ii) the 25-spp frames the
@@ -161,10 +161,33 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
         }
 
     anim = run("graph", n_frames)
-    anim_host = run("host", min(n_frames, 200))
-    paused = run("paused", max(8, n_frames // 8))
+    anim_host = run("host", min(n_frames, 200)) if extra_legs else None
+    paused = run("paused", max(8, n_frames // 8)) if extra_legs else None
     st.set_flags(is_paused=False)
     canvas = loop.canvas
+    # The dominant kernel of the animation loop on its own: the trace launch of one GROUP of 16 frames (16 passes of 1 spp,
+    # pass k at u_time = now + k * interval, exactly the launch pt_render_frames captures), timed with HIP events on the
+    # launch stream around that kernel alone (PtStats.render_kernel_ms) — what bench.py's `roofline` prices.
+    group = 16
+    p = st.to_params(3000.0)
+    p.time_step, p.first_pass = 16.7, 0
+    loop.tracer.set_params(p)
+    loop.tracer.reserve_passes(group)
+    for rep in range(3):
+        loop.tracer.reset()
+        n_launch = 4 if rep < 2 else 24
+        for _ in range(n_launch):
+            loop.tracer.render_passes(group)
+        loop.tracer.synchronize()
+    sg = loop.tracer.stats()
+    n_pix = width * height
+    group_kernel = {
+        "kernel": "pt_trace_kernel_small_t%d" % (n_sph % 4),
+        "passes_per_launch": group, "spp_per_pass": 1, "launches": int(sg.render_launches),
+        "avg_launch_ms": round(sg.render_kernel_ms / max(sg.render_launches, 1), 5),
+        "segments_per_launch": round(sg.segments / max(sg.render_launches, 1), 1),
+        "n_spheres": int(n_sph), "pixels": n_pix,
+    }
     loop.close()
     out = {
         "metric": "frames/s of the reference's animation loop (1 spp per tick, temporal blend) at %dx%d" % (width, height),
@@ -180,15 +203,17 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "State::default (%d spheres; the shader holds at most 15, static/shader.frag:103), %dx%d, depth 8, "
+            "workload": "default: State::default (%d spheres; the shader holds at most 15, static/shader.frag:103), %dx%d, depth 8, "
                         "1 spp per frame blended into RGBA8 ping-pong textures (src/state.rs:127-135, src/lib.rs:65-104, "
                         "src/webgl.rs:180-205)" % (n_sph, width, height),
             "step": "one animation frame",
+            "passes_per_launch": group, "spp_per_pass": 1,  # the trace launch of one group of frames (profiles/summarize.py keys on these)
         },
         "reference_claim": "\"less than a second\" for a decent render (README.md:6): the only performance statement the reference makes",
         "animation": anim,
         "animation_issued_per_frame_from_the_host": anim_host,
         "paused_25spp": paused,
+        "group_trace_kernel": group_kernel,
         "canvas_mean_rgb": [round(float(x), 3) for x in canvas[..., :3].reshape(-1, 3).mean(0)],
     }
     return out

@@ -208,3 +208,23 @@ def test_ipc_mode_is_set_for_every_launch_style():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
     assert line["ipc_mode_legacy"] == "1"
+
+
+def test_frame_loop_cpu_baseline_replays_the_reference_ticks():
+    """bench.py --config default's `cpu_baseline` leg (the oracle replaying the animation loop: one 1-spp pass +
+    the shader's blend per tick) on a tiny budget: whole frames, frames/s, the cores it used.  CPU only."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    keep = os.environ.get("PT_ORACLE_LIB")
+    try:
+        c = bench.frame_loop_cpu_baseline({}, budget_s=0.2, min_frames=2)
+    finally:
+        if keep is None:
+            os.environ.pop("PT_ORACLE_LIB", None)
+        else:
+            os.environ["PT_ORACLE_LIB"] = keep
+    assert c["unit"] == "frames/s" and c["value"] > 0 and c["mray_s"] > 0 and c["cores"] >= 1 and c["kind"] == "port"
+    assert c["sample"].split()[0].isdigit() and int(c["sample"].split()[0]) >= 2
