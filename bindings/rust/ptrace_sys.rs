@@ -63,6 +63,9 @@ extern "C" {
     pub fn pt_last_error(ctx: *mut PtCtx) -> *const c_char;
     pub fn pt_abi_version() -> c_int;
     pub fn pt_device_count() -> c_int;
+    // multi-GPU from one host process: the row arithmetic of the band partition
+    pub fn pt_local_rows(height: u32, band_rows: u32, band_index: u32, band_count: u32) -> u32;
+    pub fn pt_band_row(band_rows: u32, band_index: u32, band_count: u32, local_row: u32) -> u32;
 }
 
 pub const PT_OPT_GEOMETRY_PATH: c_int = 1;      // PT_GEOM_AUTO 0 / LDS 1 / SCALAR 2 / BVH 3 / GRID 4 / SMALL 5

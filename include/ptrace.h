@@ -359,6 +359,11 @@ int pt_device_count(void);
 int pt_probe(pt_ctx* ctx, int kind, const float* in, size_t n_in, float* out, size_t n_out,
              uint32_t n);
 uint32_t pt_local_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count);
+/* The image row (0 = bottom) that local row `local_row` of band `band_index` is: rank r of n owns the rows y with
+ * (y / band_rows) % n == r, in ascending order (PtParams.band_*).  What a host needs to put gathered per-rank buffers
+ * back into image order (examples/render_bands.c): row l of rank r goes to image row
+ * pt_band_row(band_rows, r, n, l), for l < pt_local_rows(height, band_rows, r, n).  Pure arithmetic, no device. */
+uint32_t pt_band_row(uint32_t band_rows, uint32_t band_index, uint32_t band_count, uint32_t local_row);
 
 /* ---- host-side camera derivation: State::update_pipeline (src/state.rs:319-347) ----------------
  * Double precision throughout, narrowed to float at the end like Vec3::to_array

@@ -55,6 +55,7 @@ SIGNATURES = {
     "pt_device_count": (C.c_int, []),
     "pt_probe": (C.c_int, [_ctx, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.c_uint32]),
     "pt_local_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_band_row": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pt_camera_from_state": (C.c_int, [C.POINTER(abi.PtCameraIn), C.POINTER(abi.PtParams)]),
     "pt_camera_look_at": (C.c_int, [C.POINTER(abi.PtLookAtIn), C.POINTER(abi.PtParams)]),
     "pt_narrow_spheres": (C.c_int, [C.POINTER(abi.PtHostSphere), C.c_uint32, C.POINTER(abi.PtSphere)]),

@@ -273,6 +273,12 @@ PT_API uint32_t pt_local_rows(uint32_t height, uint32_t band_rows, uint32_t band
   return n;
 }
 
+PT_API uint32_t pt_band_row(uint32_t band_rows, uint32_t band_index, uint32_t band_count, uint32_t local_row) {
+  if (band_count <= 1 || band_rows == 0) return local_row;
+  // local rows come in runs of band_rows: run k of this band is image band k * band_count + band_index
+  return (local_row / band_rows * band_count + band_index) * band_rows + local_row % band_rows;
+}
+
 PT_API int pt_abi_version(void) { return PT_ABI_VERSION; }
 
 // ---- pt_state: the reference's State behind an opaque handle ----------------------------------

@@ -179,7 +179,9 @@ def test_local_rows_helpers(lib):
                 tot = 0
                 for r in range(world):
                     n = lib.pt_local_rows(h, band, r, world)
-                    assert n == abi.local_rows(h, band, r, world) == len(abi.owned_rows(h, band, r, world))
+                    ys = abi.owned_rows(h, band, r, world)
+                    assert n == abi.local_rows(h, band, r, world) == len(ys)
+                    assert [lib.pt_band_row(band, r, world, l) for l in range(n)] == [int(y) for y in ys]
                     tot += n
                 assert tot == h
 
@@ -208,7 +210,7 @@ def test_rust_binding_lists_the_render_abi():
                  "pt_resolve_rgba8", "pt_blend_rgba8", "pt_accum_ptr", "pt_bind_accum", "pt_read_accum", "pt_load_accum",
                  "pt_set_stream", "pt_set_option", "pt_tune", "pt_clear_textures", "pt_render_frame", "pt_render_frames",
                  "pt_read_canvas", "pt_read_texture", "pt_write_texture",
-                 "pt_last_error", "pt_abi_version", "pt_device_count"]:
+                 "pt_last_error", "pt_abi_version", "pt_device_count", "pt_local_rows", "pt_band_row"]:
         r = re.search(r"pub fn %s\(([^)]*)\)" % name, text)
         h = re.search(r"\b%s\s*\(([^)]*)\)" % name, header)
         assert r and h, name
