@@ -265,6 +265,24 @@ def load_digests():
         return {}
 
 
+def setup_times(pt):
+    """The library's own host clocks inside pt_create / pt_set_spheres / pt_reserve_passes (include/ptrace_dev.h), ms."""
+    import ctypes as C
+
+    names = ["pt_create.hip_runtime_start", "pt_create.device_and_properties", "pt_create.stream_and_counters", "pt_create.kernel_attributes_and_code_object_load",
+             "pt_create.buffers", "pt_create.total", "pt_set_spheres.split_records", "pt_set_spheres.hierarchy_build", "pt_set_spheres.grid_build",
+             "pt_set_spheres.allocations_and_uploads", "pt_set_spheres.total", "pt_reserve_passes.total"]
+    try:
+        fn = pt.lib.pt_debug_setup_times
+    except AttributeError:
+        return {}
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
+    buf = (C.c_double * len(names))()
+    n = fn(pt._ctx, buf, len(names))
+    return {"library_ms": {names[k]: round(buf[k], 3) for k in range(max(n, 0))}}
+
+
 def plan_steps(converged_spp, spp_per_pass, passes_per_step, steps):
     """(steps, spp per step): the default step count is the config's converged frame."""
     spp_step = spp_per_pass * passes_per_step
@@ -402,8 +420,11 @@ def main():
     sync_all()
     tf0 = time.perf_counter()
     pt = PathTracer(p.width, p.height, device=local_rank, use_torch=True)
+    tfa = time.perf_counter()
     pt.set_spheres(sc.spheres)  # upload + hierarchy and grid builds
+    tfb = time.perf_counter()
     pt.set_params(p)
+    tfc = time.perf_counter()
     pt.reserve_passes(reserve)
     tf1 = time.perf_counter()
     # settle how PHASE 1 looks at the sphere list (list walks, hierarchy, grid: bit-identical
@@ -435,10 +456,16 @@ def main():
             "set_scene_ms": round((tf1 - tf0) * 1e3, 2),
             "autotune_ms": round((tf2 - tf1) * 1e3, 2),
             "cold_frame_ms": round((tf3 - tf2) * 1e3, 2),
-            "note": "context (in a fresh process 0.1-0.2 s of this is the HIP runtime and code-object load; a second context takes 3 ms: "
-                    "tools/cold_start.py) + scene upload + structure builds + workspace; pt_tune (one cold and one measured %d-pass launch per "
+            # set_scene_ms = the four calls below (host clock around each); inside pt_create and pt_set_spheres the library's own
+            # host clocks (include/ptrace_dev.h pt_debug_setup_times)
+            "set_scene_breakdown": dict(
+                {"context_ms": round((tfa - tf0) * 1e3, 2), "set_spheres_ms": round((tfb - tfa) * 1e3, 2),
+                 "set_params_ms": round((tfc - tfb) * 1e3, 2), "reserve_passes_ms": round((tf1 - tfc) * 1e3, 2)},
+                **setup_times(pt)),
+            "note": "context (PathTracer: pt_create + torch buffer + stream binding; in a fresh process most of pt_create is the HIP runtime coming up and the code "
+                    "object loading: a second context takes 3 ms, tools/cold_start.py) + scene upload + structure builds + workspace (%d slabs); pt_tune (one cold and one measured %d-pass launch per "
                     "geometry path whose outcome is open: none on an even grid); the first %d-spp frame with no tile-order feedback from a launch of its own shape (rank 0's share)"
-                    % (tune_passes, k_frame * spp_step),
+                    % (reserve, tune_passes, k_frame * spp_step),
         }
         pt.reset()
 

@@ -22,6 +22,15 @@ long pt_debug_counters(pt_ctx* ctx, unsigned long long* out, size_t cap);
  * | HW_REG_XCC_ID << 32.  `out` holds 4 * cap_waves values.  Returns the number of waves written (at most
  * cap_waves), < 0 when there is no log. */
 long pt_debug_wave_log(pt_ctx* ctx, unsigned long long* out, size_t cap_waves);
+/* Where the set-up calls of this context spent their time, host clock, milliseconds (bench.py's `first_frame`):
+ * pt_create: the process's first HIP call (runtime start; ~0 in a process that has used HIP before), device selection
+ * + properties, stream + counter allocations, the kernel attributes (the first of them loads the library's main code
+ * object onto the device), accumulation / slab / texture buffers, total; the last pt_set_spheres: splitting the records,
+ * hierarchy build, grid build, allocations + uploads, total; the last pt_reserve_passes.  Returns the number written. */
+enum { PT_SETUP_CREATE_RUNTIME = 0, PT_SETUP_CREATE_DEVICE, PT_SETUP_CREATE_STREAM_ALLOCS, PT_SETUP_CREATE_CODE_OBJECT,
+       PT_SETUP_CREATE_BUFFERS, PT_SETUP_CREATE_TOTAL, PT_SETUP_SPHERES_SPLIT, PT_SETUP_SPHERES_BVH_BUILD,
+       PT_SETUP_SPHERES_GRID_BUILD, PT_SETUP_SPHERES_UPLOAD, PT_SETUP_SPHERES_TOTAL, PT_SETUP_RESERVE_TOTAL, PT_SETUP_COUNT };
+long pt_debug_setup_times(pt_ctx* ctx, double* out_ms, size_t cap);
 /* Watchdog for the A/B tools (tools/ab_kernels.py, tools/sweep_knobs.py, ...): waits for everything
  * enqueued on the context's stream WITHOUT blocking in the driver — an event is recorded and polled
  * (hipEventQuery, 1 ms apart) until it has fired or timeout_ms have passed.  Returns 0 when the stream

@@ -125,10 +125,16 @@ struct pt_ctx {
   // device properties
   int num_cus = 256;
   int max_lds = 65536;
+  // host-clock durations of the set-up calls, ms (include/ptrace_dev.h pt_debug_setup_times: where a first frame's time goes)
+  double setup_ms[PT_SETUP_COUNT] = {0};
   std::string error;
 };
 
 namespace {
+
+inline double host_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int fail(pt_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -316,9 +322,11 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   *out = nullptr;
   if (width == 0 || height == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: empty image");
   int n = 0;
+  const double t_begin = host_ms();
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(nullptr, PT_ERR_NO_DEVICE,
                 "pt_create: no HIP device (libptrace has no CPU backend by design)");
+  const double t_runtime = host_ms();  // (the process's first HIP call brings the runtime up)
   if (device < 0 || device >= n)
     return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: device %d out of range (0..%d)", device, n - 1);
   pt_ctx* c = new (std::nothrow) pt_ctx();
@@ -338,6 +346,7 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->max_lds = (int)prop.sharedMemPerBlock;
+  const double t_device = host_ms();
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreateWithFlags");
   c->stream = c->own_stream;
@@ -348,7 +357,9 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   if ((e = hipMalloc(&c->d_frame_ctr, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(frame counter)");
   if ((e = hipMemsetAsync(c->d_frame_ctr, 0, 2 * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(frame counter)");
+  const double t_small_allocs = host_ms();
   // allow the trace kernel to use the CU's whole 160 KiB LDS for big sphere lists
+  // (the first hipFuncSetAttribute of a process also LOADS this translation unit's code object onto the device)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel),
                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_kernel_scalar),
@@ -362,8 +373,16 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   for (const void* k : {PT_KFN(pt_trace_kernel_grid), PT_KFN(pt_trace_kernel_grid_cells), PT_KFN(pt_trace_kernel_grid_gmem)})
     (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16);
   (void)hipGetLastError(); // a refused attribute only limits that kernel to the default 64 KiB; the launch code checks sizes
+  const double t_code = host_ms();
   int rc = ensure_buffers(c);
   if (rc != PT_OK) { g_create_error = c->error; delete c; return rc; }
+  const double t_end = host_ms();
+  c->setup_ms[PT_SETUP_CREATE_RUNTIME] = t_runtime - t_begin;
+  c->setup_ms[PT_SETUP_CREATE_DEVICE] = t_device - t_runtime;
+  c->setup_ms[PT_SETUP_CREATE_STREAM_ALLOCS] = t_small_allocs - t_device;
+  c->setup_ms[PT_SETUP_CREATE_CODE_OBJECT] = t_code - t_small_allocs;
+  c->setup_ms[PT_SETUP_CREATE_BUFFERS] = t_end - t_code;
+  c->setup_ms[PT_SETUP_CREATE_TOTAL] = t_end - t_begin;
   *out = c;
   return PT_OK;
 }
@@ -419,6 +438,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     return fail(c, PT_ERR_CAPACITY, "pt_set_spheres: %u spheres exceed the 16-bit candidate index range (%u)",
                 n, PT_MAX_SPHERES);
   PT_HIP(c, hipSetDevice(c->device));
+  const double t_begin = host_ms();
   if (n > c->sphere_cap || !c->d_geom) {
     if (c->d_geom) PT_HIP(c, hipFree(c->d_geom));
     if (c->d_mat) PT_HIP(c, hipFree(c->d_mat));
@@ -457,9 +477,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     mat[i].uuid = s[i].uuid;
     radii[i] = s[i].radius;
   }
+  const double t_split = host_ms();
   // the culling hierarchy of PT_GEOM_BVH (regular scenes of at least 16 spheres)
   ptbvh::Bvh bvh;
   const bool have_bvh = regular && ptbvh::build(geom.data(), radii.data(), n, &bvh);
+  const double t_bvh = host_ms();
   // ... and the uniform grid of PT_GEOM_GRID (same precondition)
   ptgrid::Grid grid;
   const bool have_grid = regular && ptgrid::build(geom.data(), radii.data(), n, &grid);
@@ -471,6 +493,10 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
 #endif
     if (mode) (void)ptgrid::morton_runs(&grid, mode != 2, mode != 3);
   }
+  const double t_grid = host_ms();
+  c->setup_ms[PT_SETUP_SPHERES_SPLIT] = t_split - t_begin;
+  c->setup_ms[PT_SETUP_SPHERES_BVH_BUILD] = t_bvh - t_split;
+  c->setup_ms[PT_SETUP_SPHERES_GRID_BUILD] = t_grid - t_bvh;
   {
     // the stream may still be reading the previous scene
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -562,6 +588,11 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   c->scene_regular = regular;
   c->have_spheres = true;
   list_paths(c);
+  {
+    const double t_end = host_ms();
+    c->setup_ms[PT_SETUP_SPHERES_UPLOAD] = t_end - t_grid;
+    c->setup_ms[PT_SETUP_SPHERES_TOTAL] = t_end - t_begin;
+  }
   return PT_OK;
 }
 
@@ -632,12 +663,15 @@ PT_API int pt_resize(pt_ctx* c, uint32_t width, uint32_t height) {
 PT_API int pt_reserve_passes(pt_ctx* c, uint32_t max_passes) {
   if (!c || max_passes == 0) return fail(c, PT_ERR_INVALID, "pt_reserve_passes: bad argument");
   PT_HIP(c, hipSetDevice(c->device));
+  const double t_begin = host_ms();
   if (max_passes > c->reserved_passes) {
     PT_HIP(c, hipStreamSynchronize(c->stream));
     c->reserved_passes = max_passes;
     c->epoch++;  // the slab may move
   }
-  return ensure_buffers(c);
+  const int rc = ensure_buffers(c);
+  c->setup_ms[PT_SETUP_RESERVE_TOTAL] = host_ms() - t_begin;
+  return rc;
 }
 
 PT_API int pt_reset_accum(pt_ctx* c) {
@@ -1449,6 +1483,13 @@ PT_API long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_wav
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
   const size_t n = c->wave_log_n < cap_waves ? c->wave_log_n : cap_waves;
   if (hipMemcpy(out, c->d_wave_log, n * PT_WAVE_LOG_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long)n;
+}
+
+PT_API long pt_debug_setup_times(pt_ctx* c, double* out_ms, size_t cap) {
+  if (!c || !out_ms) return -1;
+  const size_t n = cap < (size_t)PT_SETUP_COUNT ? cap : (size_t)PT_SETUP_COUNT;
+  for (size_t k = 0; k < n; k++) out_ms[k] = c->setup_ms[k];
   return (long)n;
 }
 

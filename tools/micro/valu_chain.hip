@@ -55,7 +55,8 @@ static void wait_or_leave(const char* what, int w) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
       printf("\nWATCHDOG: %s at %d waves per SIMD did not finish within 5 s\n", what, w);
       fflush(stdout);
-      _exit(3);
+      (void)hipEventDestroy(ev);  // (non-blocking; the buffer is NOT freed: hipFree waits for the device, i.e. for the very
+      _exit(3);                   //  kernel that does not end — leaving the process is what takes its queue off the GPU)
     }
     usleep(200);
   }
