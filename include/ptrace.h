@@ -296,7 +296,10 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
  * state of State::update_render_globals (src/state.rs:443-450) kept on the device: frame k of the
  * call renders at u_time = time + float(first_pass + k) * time_step with
  * render_count = min(params.render_count + k, max_render_count) and even_odd_count + k — the bits
- * of n_frames pt_render_frame calls made with those uniforms.  That equals n_frames ticks of the
+ * of n_frames pt_render_frame calls made with those uniforms (u_time is fp32(time) + float(k) * fp32(time_step),
+ * computed in fp32 on the device: it equals fp32(time + k * time_step) rounded from the host's f64 — what a tick-by-tick
+ * host uploads — for every k only when time, time_step and their products are exact in fp32, e.g. whole or half
+ * milliseconds; otherwise some frames get a neighbouring seed: equally valid samples, not the same bits).  That equals n_frames ticks of the
  * reference's loop only while nothing but the clock changes between them: with should_average off
  * just the first tick draws (update_render_globals clears should_render, src/state.rs:443-447), with a
  * movement key held every tick has its own camera — issue such ticks one by one (pt_render_frame).

@@ -87,17 +87,48 @@ SIGNATURES = {
 }
 
 
-def _share_torch_hip_runtime():
+def _elf_dynamic_strings(path, tags):
+    """The strings of an ELF64 shared object's dynamic section for the given tags (1 = DT_NEEDED, 14 = DT_SONAME)."""
+    import struct
+
+    out = []
+    with open(path, "rb") as f:
+        hdr = f.read(64)
+        if hdr[:4] != b"\x7fELF" or hdr[4] != 2 or hdr[5] != 1:
+            return out
+        shoff, = struct.unpack_from("<Q", hdr, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", hdr, 0x3A)
+        f.seek(shoff)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", f.read(shentsize)) for _ in range(shnum)]
+        for sec in secs:
+            if sec[1] != 6:  # SHT_DYNAMIC
+                continue
+            strtab = secs[sec[6]]  # sh_link: its string table
+            f.seek(sec[4])
+            dyn = f.read(sec[5])
+            for k in range(0, len(dyn) - 15, 16):
+                tag, val = struct.unpack_from("<qQ", dyn, k)
+                if tag in tags:
+                    f.seek(strtab[4] + val)
+                    out.append(f.read(256).split(b"\0", 1)[0].decode("ascii", "replace"))
+    return out
+
+
+def _share_torch_hip_runtime(lib_path):
     """One HIP runtime per process.  libptrace.so needs libamdhip64.so.7; PyTorch ships its own copy of that
     library.  Whichever is loaded first serves both (same SONAME) — as long as it is PyTorch's: with the system
     copy loaded first, a later `import torch` brings its own runtime as a second one, and the second runtime to
     touch the GPU finds none ("No HIP GPUs are available" from PathTracer(use_torch=True), dist.py or bench.py,
     depending on import order).  So if PyTorch is installed but not imported yet, its copy is loaded here, before
-    libptrace.so, exactly as if `import torch` had come first.  Without PyTorch the system runtime is used."""
+    libptrace.so, exactly as if `import torch` had come first — but ONLY when its SONAME is the one libptrace.so asks
+    for (DT_NEEDED): a PyTorch built for another ROCm major (libamdhip64.so.6) could never serve libptrace, and
+    preloading it would CREATE the two-runtime process this function exists to avoid.  Without PyTorch, with a
+    mismatching one, or with PT_NO_TORCH_HIP_PRELOAD set, the system runtime the library was built against is used
+    (and PathTracer(use_torch=True) reports the mismatch when it is asked to share buffers with torch)."""
     import importlib.util
     import sys
 
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("PT_NO_TORCH_HIP_PRELOAD"):
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -106,11 +137,19 @@ def _share_torch_hip_runtime():
     if spec is None or not spec.origin:
         return
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(path):
-        try:
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # (an unusable copy: the system runtime serves libptrace.so, and use_torch will say what is wrong)
+    if not os.path.exists(path):
+        return
+    try:
+        wanted = [n for n in _elf_dynamic_strings(lib_path, (1,)) if n.startswith("libamdhip64.so")]
+        offered = _elf_dynamic_strings(path, (14,))
+    except (OSError, ValueError, IndexError):
+        return
+    if not wanted or not offered or offered[0] != wanted[0]:
+        return  # another ROCm major (or an unreadable file): leave it alone
+    try:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # (an unusable copy: the system runtime serves libptrace.so, and use_torch will say what is wrong)
 
 
 def load():
@@ -118,13 +157,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    _share_torch_hip_runtime()
     path = os.environ.get("PT_LIB", LIB_PATH)  # dev: A/B another build of the same ABI
     if not os.path.exists(path):
         raise ImportError(
             "libptrace.so not found at %s — build it with `make -C ray_tracer_webgl_amd/csrc` "
             "(there is no CPU fallback)" % path
         )
+    _share_torch_hip_runtime(path)
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

@@ -80,7 +80,12 @@ class FrameLoop:
         nothing, should_render stays true while unpaused) they are ONE pt_render_frames call: the first
         tick's uniforms go up once, the graph of one frame is replayed n times, u_time / render_count /
         even-odd advance on the device as the n calls would advance them.  Otherwise the ticks differ in
-        more than the clock — with should_average off only the first one draws (update_render_globals
+        more than the clock.  BIT-identical to the n single ticks when `first_now_ms`, `interval_ms` and their products are
+        exact in fp32 (the tests' 100.0 and 16.5; any whole or half millisecond below 2^23): the device computes
+        u_time = fp32(first_now_ms) + float(k) * fp32(interval_ms), a single tick uploads fp32(first_now_ms + k * interval_ms)
+        rounded from f64 (gl.uniform1f(now as f32), src/webgl.rs:322).  For a real rAF interval like 16.6667 the two differ in
+        the last bit for some k: other seeds, so other — statistically equivalent — samples.  Ticks that differ in more than
+        the clock are never replayed: with should_average off only the first one draws (update_render_globals
         clears should_render, src/state.rs:443-447), with a key held every tick moves the camera
         (update_position, src/state.rs:411-441) — and they are issued one by one.  Reference mode only."""
         assert self.mode == "reference" and n >= 1

@@ -625,14 +625,17 @@ PT_API int pt_set_params(pt_ctx* c, const PtParams* p) {
       c->local_rows = old_rows;
       return rc;
     }
-    // a different set of rows: the accumulated image no longer applies, and neither do the frame textures
-    PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
-    {
-      int rc2 = pt_clear_textures(c);
-      if (rc2 != PT_OK) return rc2;
-    }
+    // From here on the new partition is in place (buffers sized for it), so the STATE is committed before the fallible
+    // clears below: whatever they return, local_rows, params.band_* and the sample count agree with each other
+    // (a refused clear leaves a self-consistent context whose old image is gone, never a new partition with old uniforms).
+    c->params = *p;
+    c->have_params = true;
+    c->epoch++;
     c->total_spp = 0;
     c->captured = false;  // whatever a replayed graph accumulated is gone with the old partition
+    // a different set of rows: the accumulated image no longer applies, and neither do the frame textures
+    PT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->local_rows * c->width * sizeof(float4), c->stream));
+    return pt_clear_textures(c);
   }
   c->params = *p;
   c->have_params = true;
@@ -833,7 +836,8 @@ static int fill_uniforms(pt_ctx* c, uint32_t n_passes, PtKernelArgs& A) {
   A.coop_max_live = 16;
   A.carry_lanes = c->carry_lanes;
   A.refill_min = c->refill_min;
-#ifdef PT_DEV_KNOBS // A/B builds only (tools/sweep_knobs.py); the product reads no environment
+#ifdef PT_DEV_KNOBS // A/B builds only (tools/sweep_knobs.py); libptrace.so as shipped reads no environment variable (the Python
+                    // harness has ONE, PT_LIB: which build of this library ray_tracer_webgl_amd/_lib.py loads — a loader matter)
   if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
 #endif
   // cost feedback for the next launch's tile order: one atomicMax per item of pass 0.  A launch of one
@@ -1379,16 +1383,22 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     uint32_t left = n_frames;
     for (int g = 0; g < 3; g++) { counts[g] = left / kFrameGroups[g]; left -= counts[g] * kFrameGroups[g]; }
   }
-  const uint32_t biggest = counts[0] ? kFrameGroups[0] : (counts[1] ? kFrameGroups[1] : 1u);
-  if (biggest > 1u) {  // the groups' own slabs (never the slab of pt_render_passes: a caller's captured launches keep theirs)
-    const size_t need = (size_t)c->local_rows * c->width * biggest;
-    if (c->frame_slab_pixels < need) {  // first use at this size: the one allocation this entry point ever makes
-      PT_HIP(c, hipStreamSynchronize(c->stream));
-      if (c->d_frame_slab) PT_HIP(c, hipFree(c->d_frame_slab));
-      c->d_frame_slab = nullptr; c->frame_slab_pixels = 0;
-      PT_HIP(c, hipMalloc(&c->d_frame_slab, need * sizeof(float4)));
-      c->frame_slab_pixels = need;
-    }
+  // the groups' own slabs (never the slab of pt_render_passes: a caller's captured launches keep theirs): the one allocation
+  // this entry point ever makes, at the first use of a size.  16 x local_rows x width x 16 B is 230 MB at the reference's
+  // 1280x702 and 2.1 GB at 4K; when it cannot be had the series falls back to groups of 4 (a quarter of it) and then to
+  // single frames out of the slab every context owns — slower, never a failed call.
+  for (int g = 0; g < 2; g++) {
+    if (!counts[g]) continue;
+    const size_t need = (size_t)c->local_rows * c->width * kFrameGroups[g];
+    if (c->frame_slab_pixels >= need) break;
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_frame_slab) PT_HIP(c, hipFree(c->d_frame_slab));
+    c->d_frame_slab = nullptr; c->frame_slab_pixels = 0;
+    if (hipMalloc(&c->d_frame_slab, need * sizeof(float4)) == hipSuccess) { c->frame_slab_pixels = need; break; }
+    (void)hipGetLastError();  // out of memory is not an error of this call: deal this group's frames to the next smaller one
+    c->d_frame_slab = nullptr;
+    counts[g + 1] += counts[g] * (kFrameGroups[g] / kFrameGroups[g + 1]);
+    counts[g] = 0;
   }
   rc = ensure_tile_order(c);  // outside the capture: it runs once, not per frame
   if (rc != PT_OK) return rc;
