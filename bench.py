@@ -271,7 +271,8 @@ def setup_times(pt):
 
     names = ["pt_create.hip_runtime_start", "pt_create.device_and_properties", "pt_create.stream_and_counters", "pt_create.kernel_attributes_and_code_object_load",
              "pt_create.buffers", "pt_create.total", "pt_set_spheres.split_records", "pt_set_spheres.hierarchy_build", "pt_set_spheres.grid_build",
-             "pt_set_spheres.allocations_and_uploads", "pt_set_spheres.total", "pt_reserve_passes.total"]
+             "pt_set_spheres.allocations_and_uploads", "pt_set_spheres.total", "pt_reserve_passes.total",
+             "pt_create.stream_and_counters.hipStreamCreate", "pt_create.stream_and_counters.first_hipMalloc", "pt_create.stream_and_counters.first_hipMemsetAsync"]
     try:
         fn = pt.lib.pt_debug_setup_times
     except AttributeError:

@@ -22,6 +22,11 @@ long pt_debug_counters(pt_ctx* ctx, unsigned long long* out, size_t cap);
  * | HW_REG_XCC_ID << 32.  `out` holds 4 * cap_waves values.  Returns the number of waves written (at most
  * cap_waves), < 0 when there is no log. */
 long pt_debug_wave_log(pt_ctx* ctx, unsigned long long* out, size_t cap_waves);
+/* The grid twins' gather statistics of the last counted launch (every 8th wave sampled): out[0 .. n_entries) = leaf-round
+ * lanes per entry-run start (index into the grid's entry array), then 66 values: bins 0..64 = leaf rounds with that many
+ * DISTINCT runs among their lanes, [65] = the sampled rounds' lanes.  Returns the number of values written (n_entries + 66
+ * when cap allows), < 0 when there is none. */
+long pt_debug_cell_hist(pt_ctx* ctx, uint32_t* out, size_t cap);
 /* Where the set-up calls of this context spent their time, host clock, milliseconds (bench.py's `first_frame`):
  * pt_create: the process's first HIP call (runtime start; ~0 in a process that has used HIP before), device selection
  * + properties, stream + counter allocations, the kernel attributes (the first of them loads the library's main code
@@ -29,7 +34,8 @@ long pt_debug_wave_log(pt_ctx* ctx, unsigned long long* out, size_t cap_waves);
  * hierarchy build, grid build, allocations + uploads, total; the last pt_reserve_passes.  Returns the number written. */
 enum { PT_SETUP_CREATE_RUNTIME = 0, PT_SETUP_CREATE_DEVICE, PT_SETUP_CREATE_STREAM_ALLOCS, PT_SETUP_CREATE_CODE_OBJECT,
        PT_SETUP_CREATE_BUFFERS, PT_SETUP_CREATE_TOTAL, PT_SETUP_SPHERES_SPLIT, PT_SETUP_SPHERES_BVH_BUILD,
-       PT_SETUP_SPHERES_GRID_BUILD, PT_SETUP_SPHERES_UPLOAD, PT_SETUP_SPHERES_TOTAL, PT_SETUP_RESERVE_TOTAL, PT_SETUP_COUNT };
+       PT_SETUP_SPHERES_GRID_BUILD, PT_SETUP_SPHERES_UPLOAD, PT_SETUP_SPHERES_TOTAL, PT_SETUP_RESERVE_TOTAL,
+       /* inside PT_SETUP_CREATE_STREAM_ALLOCS: */ PT_SETUP_CREATE_STREAM, PT_SETUP_CREATE_FIRST_MALLOC, PT_SETUP_CREATE_FIRST_MEMSET, PT_SETUP_COUNT };
 long pt_debug_setup_times(pt_ctx* ctx, double* out_ms, size_t cap);
 /* Watchdog for the A/B tools (tools/ab_kernels.py, tools/sweep_knobs.py, ...): waits for everything
  * enqueued on the context's stream WITHOUT blocking in the driver — an event is recorded and polled

@@ -34,7 +34,7 @@ cat $OUT/summary.txt
 fi  # PT_COLLECT_MAIN=0 skips the config-2 part (PT_COLLECT_CONFIGS="4" re-collects one config)
 # the other BASELINE configs through the same bench line, each with its own kernel trace and PMC passes: the records
 # bench.py attaches to `--config 3 / 4 / 5` lines (profiles/summarize.py --merge <dirs> writes profiles/pmc_traffic.json)
-for CFG in ${PT_COLLECT_CONFIGS:-3 4 5 default}; do
+for CFG in ${PT_COLLECT_CONFIGS-3 4 5 default}; do  # (PT_COLLECT_CONFIGS="" collects config 2 only)
   OC=gpurun_out/prof_${TAG}_c$CFG
   mkdir -p $OC
   BC="python3 bench.py --config $CFG --no-cpu-baseline --no-work-count --no-list-walk --no-first-frame"

@@ -92,6 +92,8 @@ struct pt_ctx {
   size_t grid_cell_cap = 0, grid_entry_cap = 0;
   ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
   int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
+  uint32_t* d_cell_hist = nullptr;           // grid twins: leaf-round lanes per entry run + coherence bins (pt_debug_cell_hist)
+  size_t cell_hist_cap = 0, cell_hist_n = 0;
   unsigned long long* d_wave_log = nullptr;  // measuring twins: per-wave {start, queue dry, end}
   size_t wave_log_cap = 0, wave_log_n = 0;
   uint32_t carry_lanes = 12;
@@ -350,10 +352,13 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreateWithFlags");
   c->stream = c->own_stream;
+  const double t_stream = host_ms();
   if ((e = hipMalloc(&c->d_counters, PT_CTR_COUNT * sizeof(unsigned long long))) != hipSuccess)
     return bail(e, "hipMalloc(counters)");
+  const double t_first_malloc = host_ms();
   if ((e = hipMemsetAsync(c->d_counters, 0, PT_CTR_COUNT * sizeof(unsigned long long), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(counters)");
+  const double t_first_memset = host_ms();
   if ((e = hipMalloc(&c->d_frame_ctr, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(frame counter)");
   if ((e = hipMemsetAsync(c->d_frame_ctr, 0, 2 * sizeof(uint32_t), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(frame counter)");
@@ -380,6 +385,9 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   c->setup_ms[PT_SETUP_CREATE_RUNTIME] = t_runtime - t_begin;
   c->setup_ms[PT_SETUP_CREATE_DEVICE] = t_device - t_runtime;
   c->setup_ms[PT_SETUP_CREATE_STREAM_ALLOCS] = t_small_allocs - t_device;
+  c->setup_ms[PT_SETUP_CREATE_STREAM] = t_stream - t_device;
+  c->setup_ms[PT_SETUP_CREATE_FIRST_MALLOC] = t_first_malloc - t_stream;
+  c->setup_ms[PT_SETUP_CREATE_FIRST_MEMSET] = t_first_memset - t_first_malloc;
   c->setup_ms[PT_SETUP_CREATE_CODE_OBJECT] = t_code - t_small_allocs;
   c->setup_ms[PT_SETUP_CREATE_BUFFERS] = t_end - t_code;
   c->setup_ms[PT_SETUP_CREATE_TOTAL] = t_end - t_begin;
@@ -401,6 +409,7 @@ PT_API int pt_destroy(pt_ctx* c) {
   if (c->d_bvh_index) (void)hipFree(c->d_bvh_index);
   if (c->d_bvh_mat) (void)hipFree(c->d_bvh_mat);
   if (c->d_wave_log) (void)hipFree(c->d_wave_log);
+  if (c->d_cell_hist) (void)hipFree(c->d_cell_hist);
   if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
   if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
   if (c->d_grid_index) (void)hipFree(c->d_grid_index);
@@ -1160,6 +1169,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   if (capturing && c->count_work)
     return fail(c, PT_ERR_INVALID, "pt_render_passes: PT_OPT_COUNT_WORK (measuring twin: allocates its wave log) cannot be captured into a hipGraph");
   A.wave_log = nullptr;
+  A.cell_hist = nullptr;
   if (c->count_work && (path == PT_GEOM_BVH || path == PT_GEOM_GRID || path == PT_GEOM_SMALL)) { // measuring twin: not a product launch, may allocate
     const size_t n_waves = (size_t)grid * (block / 64);
     if (n_waves * PT_WAVE_LOG_WORDS > c->wave_log_cap) {
@@ -1171,6 +1181,18 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
     PT_HIP(c, hipMemsetAsync(c->d_wave_log, 0, n_waves * PT_WAVE_LOG_WORDS * sizeof(unsigned long long), c->stream));
     c->wave_log_n = n_waves;
     A.wave_log = c->d_wave_log;
+    if (path == PT_GEOM_GRID && c->count_work >= 2) {  // which entry runs the leaf rounds gather (config 5's cache model, tools/config5_cache_model.py)
+      const size_t n_hist = (size_t)A.n_slots + PT_COH_BINS;
+      if (n_hist > c->cell_hist_cap) {
+        if (c->d_cell_hist) PT_HIP(c, hipFree(c->d_cell_hist));
+        c->d_cell_hist = nullptr; c->cell_hist_cap = 0;
+        PT_HIP(c, hipMalloc(&c->d_cell_hist, n_hist * sizeof(uint32_t)));
+        c->cell_hist_cap = n_hist;
+      }
+      PT_HIP(c, hipMemsetAsync(c->d_cell_hist, 0, n_hist * sizeof(uint32_t), c->stream));
+      c->cell_hist_n = n_hist;
+      A.cell_hist = c->d_cell_hist;
+    }
   }
   // (capturing: skip the timing event pair)
   if (!capturing && c->events_used == c->events.size()) {
@@ -1272,6 +1294,7 @@ int plan_frame(pt_ctx* c, const uint32_t* ctr, uint32_t even_odd0, int max_rende
   F->L.A.frame_ctr = ctr;
   F->L.A.cost_feedback = 0;  // a frame is one short launch: it keeps the tile order it finds
   F->L.A.wave_log = nullptr;
+  F->L.A.cell_hist = nullptr;
   F->ctr = ctr; F->even_odd0 = even_odd0; F->max_render_count = max_render_count;
   F->render_count0 = c->params.render_count; F->should_average = c->params.should_average;
   F->last_frame_weight = c->params.last_frame_weight;
@@ -1496,6 +1519,14 @@ PT_API long pt_debug_wave_log(pt_ctx* c, unsigned long long* out, size_t cap_wav
   return (long)n;
 }
 
+PT_API long pt_debug_cell_hist(pt_ctx* c, uint32_t* out, size_t cap) {
+  if (!c || !c->d_cell_hist || !out) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -2;
+  const size_t n = c->cell_hist_n < cap ? c->cell_hist_n : cap;
+  if (hipMemcpy(out, c->d_cell_hist, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long)n;
+}
+
 PT_API long pt_debug_setup_times(pt_ctx* c, double* out_ms, size_t cap) {
   if (!c || !out_ms) return -1;
   const size_t n = cap < (size_t)PT_SETUP_COUNT ? cap : (size_t)PT_SETUP_COUNT;
@@ -1621,7 +1652,7 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
     return PT_OK;
   }
   if (key == PT_OPT_COUNT_WORK) { // measuring twin of the walk kernels (PtStats.work); slower, never timed
-    c->count_work = value ? 1 : 0;
+    c->count_work = value < 0 ? 0 : (value > 2 ? 2 : value);  // 2 (dev tools only): the grid twins also fill the gather histogram (pt_debug_cell_hist)
     return PT_OK;
   }
   if (key == PT_OPT_REFILL_MIN) { // scheduling only, never results

@@ -138,6 +138,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
   // entry: where does the half-line meet the grid's box?
   if (!carried) { rem = 0u; pend = 0u; }
   if (pt_ballot(fresh) != 0ull) {
+    if (fresh) tally.flag(PT_REG_WALK_ENTRY);
     // near rays (|o - c0| + s0 <= d_near, tested on squares: grid_r2_near = (0.9999 d_near - s0)^2):
     // every registered box lies inside [lo, hi] (delta_g is part of it); the host has widened
     // grid_lo_n / grid_hi_n by 1e-6 d_near for the rounding of this slab arithmetic.  Far
@@ -161,12 +162,14 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
         __builtin_fmaxf(t1z, t2z));
     bool enter = fresh && tn <= __builtin_fminf(tf, closest);
     if (enter && !near) { // (rare) a ray from far away that does reach the grid
+      tally.flag(PT_REG_WALK_FAR_RAY);
       lit_from = 0u;
       closest = PT_MAX_T;
       hit_pos = 0xffffffffu;
       enter = false;
     }
     if (enter) {
+      tally.flag(PT_REG_WALK_ENTER_CELL);
       // the cell that holds the entry point (clamped: rounding may put it a hair outside)
       const float glx = K.grid_lo[0], gly = K.grid_lo[1], glz = K.grid_lo[2];
       const float ghx = K.grid_h[0], ghy = K.grid_h[1], ghz = K.grid_h[2];
@@ -227,6 +230,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
           rem = (out || ((rec >> 24) == 0u && closest < tmin)) ? 0u : rem; \
         }
     if (m_mv != 0ull) {
+      tally.walk_first();
       PT_CELL_STEP
       m_mv = pt_ballot(rem != 0u) & pt_ballot(pend < 0x1000000u);
       while (__builtin_expect(m_mv != 0ull, 0)) {
@@ -245,6 +249,7 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
       // next cell or to the slack behind the array: tested, then masked)
       const uint32_t base = pend & 0xffffffu;
       const uint32_t left = pend >> 24;
+      tally.leaf_cells(A, has, base, A.n_slots);
       const float4 g0 = S::slot_at(A, base), g1 = S::slot_at(A, base + 1u), g2 = S::slot_at(A, base + 2u), g3 = S::slot_at(A, base + 3u);
       float hb0, cc0, ds0; sphere_test(o, d, a, g0, hb0, cc0, ds0);
       float hb1, cc1, ds1; sphere_test(o, d, a, g1, hb1, cc1, ds1);

@@ -88,6 +88,8 @@ struct PtKernelArgs {
                                    // on ONE address, ~25 ns each in turn; 28 000 of them ARE the 1-spp frame's 0.78 ms)
   uint32_t n_waves;                // waves of the launch (grid x workgroup / 64)
   uint32_t cost_feedback;          // 1: pass 0's items report their length (one atomicMax each) for the next launch's tile order
+  uint32_t* cell_hist;             // COUNT twins of the grid kernels only (NULL otherwise): [n_slots] leaf-round lanes per entry-run start
+                                   // (sampled: every 8th wave), then PT_COH_BINS bins of "distinct runs among a leaf round's lanes"
   const uint32_t* frame_ctr;       // device cell added to the pass number in u_time (pt_render_frames: frames replayed from a
                                    // hipGraph advance it on the device); points at a zero cell otherwise.  Never NULL.
 };
@@ -114,8 +116,14 @@ struct PtKernelArgs {
 #define PT_WAVES_TWIN_CELLS 4 // the measuring twin of the cells-only grid kernel (98 VGPRs with its tallies live)
 #define PT_BUILT_FOR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
-enum { PT_WAVE_LOG_WORDS = 4 };  // u64 per wave in PtKernelArgs.wave_log
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
+enum { PT_WAVE_LOG_WORDS = 4 };
+enum { PT_COH_BINS = 66, PT_HIST_WAVE_STRIDE = 8 };  // cell_hist: bins 0..64 = distinct entry runs in a sampled leaf round, bin 65 = sampled rounds' lanes  // u64 per wave in PtKernelArgs.wave_log
+// regions of a wave step the measuring twins count (Tally::flag / collect): [PT_CTR_REGIONS + 2 k] wave steps in which any lane
+// ran region k, [+ 2 k + 1] lanes that did
+enum { PT_REG_REFILL_DECODE = 0, PT_REG_REFILL_RESERVE, PT_REG_CAMERA_RAY, PT_REG_SHADE_HIT_RECORD, PT_REG_SHADE_SKY, PT_REG_SHADE_DIFFUSE,
+       PT_REG_SHADE_METAL, PT_REG_SHADE_GLASS, PT_REG_SHADE_GLASS_REFRACT, PT_REG_SHADE_CONTINUES, PT_REG_SHADE_FINISHED, PT_REG_SHADE_ITEM_STORE,
+       PT_REG_WALK_ENTRY, PT_REG_WALK_ENTER_CELL, PT_REG_WALK_FAR_RAY, PT_REG_SHADE_ANY, PT_N_REGIONS };
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.

@@ -121,6 +121,7 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     }
     dealt = true;
     if (pool_next == pool_end) { // wave-uniform
+      tally.flag(PT_REG_REFILL_RESERVE);
       unsigned long long base = 0;
       if (K.queue_static != 0u) {
         // short launches: reservations are dealt round-robin, no atomics (a wave's number is the same in
@@ -158,6 +159,7 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     const uint32_t pool_base = pool_next;
     pool_next += cnt < avail ? cnt : avail;
     if (need && rank < avail) {
+      tally.flag(PT_REG_REFILL_DECODE);
       uint32_t item = pool_base + rank;
       uint32_t per_tile = 64u * K.n_passes;
       uint32_t tile_pos, tile; // heaviest tiles are dealt first (tile_order)

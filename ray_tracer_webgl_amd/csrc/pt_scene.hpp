@@ -238,10 +238,17 @@ __device__ __forceinline__ void park_load(const PtKernelArgs& A, Path& p) {
 template <bool COUNT>
 struct Tally {
   unsigned long long t_wave_start = 0, t_wave_dry = 0;
+  // which REGIONS of a wave step ran, and for how many lanes (tools/instruction_mix.py weights the kernel's ISA with these):
+  // a lane notes the regions it enters as bits of lane_flags (inside divergent code), collect() turns them into wave-level
+  // counts in uniform control flow at the end of the step
+  // (the 2 x PT_N_REGIONS counters live in ONE VGPR: lane 2 k holds region k's wave-step count, lane 2 k + 1 its lane count —
+  // as wave-uniform scalars they were 32 more SGPRs, spilled through VGPR lanes, and pushed the twins into scratch)
+  uint32_t lane_flags = 0, reg_acc = 0;
   uint32_t hw_id = 0, xcc_id = 0;  // where the wave runs: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID, read once at its start
   uint32_t tb_bin = 0xffffffffu, tb_acc = 0;
   uint32_t n_walk_it = 0, n_walk_ln = 0, n_leaf_it = 0, n_leaf_ln = 0, n_exact_it = 0, n_exact_ln = 0, n_steps = 0,
            n_carried = 0;
+  uint32_t n_walk_first = 0;  // cell steps taken through the copy written out in front of the loop (pt_grid_walk.hpp)
   uint32_t n_exact_always_it = 0, n_exact_always_ln = 0;  // (the share of the exact evaluations that serves the always-tested group)
   bool in_always = false;
   // phase clock (shader cycles, s_memtime): where a wave's time goes
@@ -259,6 +266,30 @@ struct Tally {
     }
   }
   __device__ __forceinline__ void walk(unsigned long long mask) { if constexpr (COUNT) { n_walk_it++; n_walk_ln += (uint32_t)__popcll(mask); } }
+  __device__ __forceinline__ void walk_first() { if constexpr (COUNT) n_walk_first++; }
+  // config 5's question: WHICH entry runs do the leaf rounds gather, and how many different ones per round?
+  // Every PT_HIST_WAVE_STRIDE-th wave counts, per leaf round, its lanes per run start (global histogram) and the number of distinct
+  // runs among them (how coherent is one wave-level gather).
+  __device__ __forceinline__ void leaf_cells(const PtKernelArgs& A, bool has, uint32_t base, uint32_t n_slots) {
+    if constexpr (COUNT) {
+      if (A.cell_hist == nullptr) return;
+      const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      if (wave % PT_HIST_WAVE_STRIDE != 0u) return;
+      if (has && base < n_slots) atomicAdd(&A.cell_hist[base], 1u);
+      unsigned long long left = pt_ballot(has);
+      const uint32_t lanes = (uint32_t)__popcll(left);
+      uint32_t distinct = 0;
+      while (left != 0ull) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(left));
+        left &= ~pt_ballot(has && base == b);
+        distinct++;
+      }
+      if (lane_id() == 0u) {
+        atomicAdd(&A.cell_hist[n_slots + (distinct < 64u ? distinct : 64u)], 1u);
+        atomicAdd(&A.cell_hist[n_slots + 65u], lanes);
+      }
+    }
+  }
   __device__ __forceinline__ void leaf(unsigned long long mask) { if constexpr (COUNT) { n_leaf_it++; n_leaf_ln += (uint32_t)__popcll(mask); } }
   __device__ __forceinline__ void exact(unsigned long long mask) {
     if constexpr (COUNT) {
@@ -268,6 +299,20 @@ struct Tally {
   }
   __device__ __forceinline__ void always_group(bool on) { if constexpr (COUNT) in_always = on; }
   __device__ __forceinline__ void step() { if constexpr (COUNT) n_steps++; }
+  __device__ __forceinline__ void flag(int region) { if constexpr (COUNT) lane_flags |= 1u << region; }
+  __device__ __forceinline__ void collect() {
+    if constexpr (COUNT) {
+      const unsigned long long t_in = __builtin_amdgcn_s_memtime();  // (its own ~100 instructions stay out of the phase clock)
+      const uint32_t me = lane_id();
+      for (int k = 0; k < PT_N_REGIONS; k++) {
+        const unsigned long long m = pt_ballot(((lane_flags >> k) & 1u) != 0u);
+        const uint32_t add = (me & 1u) ? (uint32_t)__popcll(m) : (m != 0ull ? 1u : 0u);
+        reg_acc += (me >> 1) == (uint32_t)k ? add : 0u;
+      }
+      lane_flags = 0u;
+      ph_mark += __builtin_amdgcn_s_memtime() - t_in;
+    }
+  }
   __device__ __forceinline__ void carried(bool c) { if constexpr (COUNT) n_carried += (uint32_t)__popcll(pt_ballot(c)); }
   // who takes PHASE 3 (the literal loop over the whole list): irregular rays, and regular ones the walk hands over
   __device__ __forceinline__ void literal(const PtKernelArgs& A, bool irregular, bool handed_over, uint32_t slab_index) {
@@ -303,6 +348,7 @@ struct Tally {
   }
   __device__ __forceinline__ void flush(const PtKernelArgs& A) {
     if constexpr (COUNT) {
+      if (lane_id() < 2u * PT_N_REGIONS && reg_acc != 0u) atomicAdd(&A.counters[PT_CTR_REGIONS + lane_id()], (unsigned long long)reg_acc);
       if (lane_id() == 0) {
         atomicAdd(&A.counters[PT_CTR_WORK + 0], (unsigned long long)n_walk_it);
         atomicAdd(&A.counters[PT_CTR_WORK + 1], (unsigned long long)n_walk_ln);
@@ -314,8 +360,10 @@ struct Tally {
         atomicAdd(&A.counters[PT_CTR_WORK + 7], (unsigned long long)n_carried);
         atomicAdd(&A.counters[PT_CTR_LITERAL + 5], (unsigned long long)n_exact_always_it);
         atomicAdd(&A.counters[PT_CTR_LITERAL + 6], (unsigned long long)n_exact_always_ln);
+        atomicAdd(&A.counters[PT_CTR_LITERAL + 7], (unsigned long long)n_walk_first);
         if (tb_acc) atomicAdd(&A.counters[PT_CTR_TIMEBINS + tb_bin], (unsigned long long)tb_acc);
         for (int k = 0; k < PT_N_PHASES; k++) atomicAdd(&A.counters[PT_CTR_PHASES + k], ph_t[k]);
+
         if (A.wave_log) {
           unsigned long long* wl = A.wave_log + (unsigned long long)PT_WAVE_LOG_WORDS * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
           wl[0] = t_wave_start; wl[1] = t_wave_dry; wl[2] = __builtin_amdgcn_s_memrealtime();

@@ -18,8 +18,9 @@ namespace ptk {
 // material record are read instead of going through the list index
 // RR: the opt-in Russian-roulette build of a kernel (PT_OPT_RUSSIAN_ROULETTE); the kernels without it
 // carry none of its code or registers
-template <typename S, bool RR>
-__device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, const Hit& h, const Carry& cw) {
+template <typename S, bool RR, bool COUNT>
+__device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, const Hit& h, const Carry& cw, Tally<COUNT>& tally) {
+  tally.flag(PT_REG_SHADE_ANY);
   // local copies, written back at the end (see pt_grid_walk.hpp: references would be memory to the
   // passes that run before inlining)
   bool alive = p.alive, new_path = p.new_path;
@@ -39,6 +40,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
   int mtype = -1;
   V3 hp = mk(0.f, 0.f, 0.f), n = hp, alb = hp; bool front = false; float fuzz = 0.f, ri = 1.f;
   if (hit >= 0) {
+    tally.flag(PT_REG_SHADE_HIT_RECORD);
     float4 g;
     if constexpr (S::TREE) { // the walk's hits come with their slot (same four floats as the list entry)
       if (hit_pos != 0xffffffffu) g = S::slot_at(A, hit_pos);
@@ -78,6 +80,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
   seed = (uint32_t)mtype <= 2u ? seed_drawn : seed;
   if (hit < 0) {
     if (sky) { // background(), :289-294
+      tally.flag(PT_REG_SHADE_SKY);
       float uy = d.y * inv;
       float t = 0.5f * (uy + 1.0f);
       float omt = 1.0f - t;
@@ -93,9 +96,11 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       V3 nd;
       bool ok = true;
       if (mtype == 0) { // DIFFUSE :212-229
+        tally.flag(PT_REG_SHADE_DIFFUSE);
         V3 ruv = normalize3(rs);
         nd = mk(n.x + ruv.x, n.y + ruv.y, n.z + ruv.z);
       } else { // METAL :232-247
+        tally.flag(PT_REG_SHADE_METAL);
         V3 refl = reflect3(d, n);
         nd = mk(fma_(fuzz, rs.x, refl.x), fma_(fuzz, rs.y, refl.y), fma_(fuzz, rs.z, refl.z));
         ok = dot3(n, nd) > 0.0f;
@@ -107,6 +112,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
         finished = true; // absorbed: return vec3(0.) :327-329
       }
     } else if (mtype == 2) { // GLASS :250-282
+      tally.flag(PT_REG_SHADE_GLASS);
       float ratio = front ? (1.0f / ri) : ri;
       V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
       float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
@@ -119,6 +125,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       if (cannot_refract || refl_amount > rnd) {
         nd = reflect3(ud, n);
       } else { // GLSL refract
+        tally.flag(PT_REG_SHADE_GLASS_REFRACT);
         float dni = dot3(n, ud);
         float k = fma_(-(ratio * ratio), fma_(-dni, dni, 1.0f), 1.0f);
         if (k < 0.0f) {
@@ -138,6 +145,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       finished = true; // unrecognised material absorbs, :284-285
     }
     if (!finished) {
+      tally.flag(PT_REG_SHADE_CONTINUES);
       a = dot3(d, d);
       depth++;
       if (depth >= A.max_depth) { // loop bound :300 exhausted -> return color :338
@@ -166,8 +174,10 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
   }
 
   if (finished) {
+    tally.flag(PT_REG_SHADE_FINISHED);
     sample++;
     if (sample >= A.spp) {
+      tally.flag(PT_REG_SHADE_ITEM_STORE);
       float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
       reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
       if (item_tile != 0xffffffffu) atomicMax(&A.tile_cost[item_tile], item_segs);

@@ -44,6 +44,7 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     // one copy of the camera-ray code per step serves both kinds of lanes: those that just
     // pulled an item and those whose previous path ended in the last step
     if (p.alive && p.new_path) {
+      tally.flag(PT_REG_CAMERA_RAY);
       start_sample(p, pd);
       p.new_path = false;
     }
@@ -103,7 +104,8 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
     const bool shade = p.alive && !cw.carried;
     seg_count += (uint32_t)__popcll(pt_ballot(shade));
     tally.timebin(A, shade);
-    if (shade) shade_segment<S, RR>(A, p, h, cw);
+    if (shade) shade_segment<S, RR>(A, p, h, cw, tally);
+    tally.collect();
     tally.phase(7);
   }
 

@@ -109,7 +109,7 @@ class PathTracer:
     def set_count_work(self, on=True):
         """Walk kernels: launch the measuring twin, which fills stats().work (executed iterations
         and active lanes per phase).  Slower; never time it."""
-        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_COUNT_WORK, 1 if on else 0))
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_COUNT_WORK, int(on)))  # (2: dev tools, + the grid twins' gather histogram)
 
     def set_carry_lanes(self, n):
         """Walk kernels: move on to shading when fewer than n lanes (and less than half the wave)

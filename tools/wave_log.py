@@ -91,6 +91,12 @@ ctr = np.zeros(128, np.uint64)
 pt.lib.pt_debug_counters.restype = C.c_long
 pt.lib.pt_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 pt.lib.pt_debug_counters(pt._ctx, ctr.ctypes.data_as(C.c_void_p), 128)
+if os.environ.get("WL_JSON"):
+    import json
+    json.dump({"what": "the measuring twin's raw counters (pt_kernel_args.h PT_CTR_*) of ONE launch: %s, %d rank(s), %d passes of %d spp" % (which, n, passes, spp),
+               "config": which, "ranks": n, "passes": passes, "spp": spp, "waves": int(k), "segments": int(st.segments), "kernel_ms": st.render_kernel_ms,
+               "grid_always": int(st.grid_always), "grid_cells": [int(x) for x in st.grid_cells], "grid_entries": int(st.grid_entries),
+               "counters": [int(x) for x in ctr]}, open(os.environ["WL_JSON"], "w"), indent=1)
 bins = ctr[64:128].astype(np.float64)
 first = int((buf[:k, 0].min() >> np.uint64(16)) & np.uint64(63))
 order = [(first + j) % 64 for j in range(64)]
