@@ -79,8 +79,10 @@ for f in glob.glob(os.path.join(d, "kt_configs.log")):
 # launch the same kernels on 8 passes; the timed launches are the long ones): a dispatch is kept when its
 # duration is within 15 % of that kernel's longest in the same pass
 ctr = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(d, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
+seen_in = defaultdict(set)  # a counter collected in two passes (two pmc directories) counts ONCE, not twice
+for f in sorted(glob.glob(os.path.join(d, "pmc*", "**", "*_counter_collection.csv"), recursive=True)):
     rows = [r for r in csv.DictReader(open(f))]
+    pass_dir = os.path.relpath(f, d).split(os.sep)[0]
     longest = defaultdict(float)
     for row in rows:
         dur = float(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
@@ -88,6 +90,10 @@ for f in glob.glob(os.path.join(d, "pmc*", "**", "*_counter_collection.csv"), re
     for row in rows:
         dur = float(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         if dur >= 0.85 * longest[row["Kernel_Name"]]:
+            key = (row["Kernel_Name"], row["Counter_Name"])
+            if seen_in[key] and pass_dir not in seen_in[key]:
+                continue  # (a counter collected in two passes: the first pass that holds it counts)
+            seen_in[key].add(pass_dir)
             ctr[row["Kernel_Name"]][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 main_kernel = None
 if ctr:

@@ -131,7 +131,9 @@ enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8
 #define PT_MAX_SPHERES_SMALL 16u   // PT_GEOM_SMALL: the whole list reaches the VALU from SGPRs, four spheres per s_load_dwordx16
 #define PT_MAX_SPHERES_LDS 10232u  // PT_LDS_ENTRIES(10232) * 16 B = 163 776 B <= 160 KiB
 #define PT_PARK_DWORDS 14u  // per-lane path state parked in LDS during the walks
+#ifndef PT_PARK_STRIDE
 #define PT_PARK_STRIDE 15u  // dwords per lane in the parking area (odd: conflict-free columns)
+#endif
 #define PT_BVH_LDS_BYTES32(n_nodes, n_slots) ((((size_t)(n_nodes) + 1u) * 2u + (size_t)(n_slots)) * 16u)
 #define PT_BVH_LDS_BYTES16(n_nodes) (((size_t)(n_nodes) + 1u) * 16u)
 #define PT_GRID_LDS_CELLS(n_cells) ((((size_t)(n_cells) + 3u) / 4u) * 16u)

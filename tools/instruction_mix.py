@@ -469,8 +469,9 @@ def main():
         # the record is per launch of `passes_per_launch` passes; the tallies file says how many passes its launch had
         scale = W * float(rec.get("passes_per_launch", 64)) / float(T.get("passes", 64))
         print("\n## cross-check: model (per wave step x %.4g wave steps per %d-pass launch) against the PMC record %s" % (scale, rec.get("passes_per_launch", 64), rec.get("profile")))
-        print("   (SQ_INSTS_SALU counts the branch instructions as well: compare it with the model's SALU + branch; SQ_INSTS_VALU_INT32 is the hardware's own class —\n"
-              "    add / mul / shift / logic on integers — and has no model row: the tool's `int` column also holds v_mbcnt, v_bitop3, v_lshl_add_u64 ...)")
+        print("   (the model counts every block of a region that ran, also sub-branches the wave skipped: an upper bound, visibly so for the scalar and branch\n"
+              "    instructions that wrap those sub-branches; SQ_INSTS_VALU_INT32 is the hardware's own class — add / mul / shift / logic on integers — and has no\n"
+              "    model row: the tool's `int` column also holds v_mbcnt, v_bitop3, v_lshl_add_u64 ...)")
         pairs = [("SQ_INSTS_VALU", "valu_insts_per_launch", vt),
                  ("SQ_INSTS_VALU_FMA_F32", "sq_insts_valu_fma_f32", dyn_tot["fp32 fma"]),
                  ("SQ_INSTS_VALU_MUL_F32", "sq_insts_valu_mul_f32", dyn_tot["fp32 mul"]),
@@ -478,7 +479,7 @@ def main():
                  ("SQ_INSTS_VALU_TRANS_F32", "sq_insts_valu_trans_f32", dyn_tot["transcendental"]),
                  ("SQ_INSTS_VALU_INT32", "sq_insts_valu_int32", None),
                  ("SQ_INSTS_VALU_CVT", "sq_insts_valu_cvt", dyn_tot["convert"]),
-                 ("SQ_INSTS_SALU (+ branches)", "sq_insts_salu", dyn_tot["SALU"] + dyn_tot["exec-mask region"] + dyn_tot["s_nop"] + dyn_tot["other scalar"] + dyn_tot["s_waitcnt"] + dyn_tot["branch"]),
+                 ("SQ_INSTS_SALU", "sq_insts_salu", dyn_tot["SALU"] + dyn_tot["exec-mask region"]),
                  ("SQ_INSTS_SMEM", "sq_insts_smem", dyn_tot["scalar load"]),
                  ("SQ_INSTS_LDS", "sq_insts_lds", dyn_tot["LDS"]),
                  ("SQ_INSTS_BRANCH", "sq_insts_branch", dyn_tot["branch"])]
