@@ -104,6 +104,11 @@ struct pt_ctx {
   uint32_t* d_tile_order = nullptr;
   size_t tile_cap = 0;
   bool tile_order_valid = false;  // d_tile_order holds an order for the current tile count
+  // the frames' cost-sorted tile order (ensure_cost_order): which view and scene it was probed for, frames drawn since
+  bool order_probed = false;
+  PtParams order_view;
+  uint64_t order_scene_gen = 0, scene_gen = 0;
+  uint32_t frames_since_probe = 0;
   // the reference's frame (pt_render_frame / pt_render_frames): two RGBA8 textures + canvas, the
   // device-side frame counter ([0] frames replayed since the series began, [1] a cell that stays 0)
   uint32_t* d_tex[2] = {nullptr, nullptr};
@@ -206,6 +211,7 @@ int ensure_buffers(pt_ctx* c) {
     }
     c->tile_cap = tiles;
     c->tile_order_valid = false;
+    c->order_probed = false;
   }
   if (c->tex_pixels < pix) {  // create_texture x2 (src/webgl.rs:82-123), cleared: alpha 0 = "no data" (shader.frag:391)
     for (int k = 0; k < 2; k++) {
@@ -592,6 +598,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   }
   c->n_spheres = n;
   c->epoch++;
+  c->scene_gen++;
   c->geom_tuned = 0;  // a new scene: PT_GEOM_AUTO measures again
   c->trial_state = 0;
   c->scene_regular = regular;
@@ -1343,6 +1350,69 @@ int ensure_tile_order(pt_ctx* c) {
   return PT_OK;
 }
 
+// ... and for frames of four samples or more it should be a COST-SORTED one.  A frame (group) is a statically dealt launch:
+// wave w takes the reservations w, w + n_waves, ... of the tile-major item list, a fixed sample of the tiles.  In the IDENTITY
+// order of a fresh context that sample is a few places of the image, and a wave's load follows what lies there (sky: one
+// segment per path, glass: eight); in an order sorted by cost it is one tile from each cost stratum and the waves' loads come
+// out nearly equal.  Frames report no costs themselves (plan_frame), so the order is PROBED: one extra pass at the current
+// uniforms with the cost feedback on, into the scratch slab, then the order kernel — outside any capture, when there is no
+// probed order yet, after a new scene or partition, and (at most every 64 frames) after the view has changed.  Measured on the
+// reference's scene and size against the identity order (profiles/r05_ab_runs.txt): the paused mode's 25-spp frame 0.870 ->
+// 0.768 ms, 8-spp frames 0.315 -> 0.275, groups of 4- / 8-spp frames 0.126 -> 0.119 / 0.212 -> 0.198 ms per frame; groups
+// of 1- and 2-spp frames +-0, and the SINGLE 1-spp frame (which runs on three workgroups per CU, four or five tiles per
+// wave) 0.083 -> 0.088-0.093: frames below four samples therefore keep — and, after a probed series, restore — the identity
+// order.  (Dealing the rounds in serpentine order, the textbook companion of a sorted list, measured +2 ... +10 % on every
+// statically dealt shape and is not used.)  Scheduling only: the probe's slab is scratch, its segment tally is taken back out
+// of the statistics.
+bool same_view(const PtParams& a, const PtParams& b) {
+  return memcmp(a.camera_origin, b.camera_origin, sizeof a.camera_origin) == 0 && memcmp(a.horizontal, b.horizontal, sizeof a.horizontal) == 0 &&
+         memcmp(a.vertical, b.vertical, sizeof a.vertical) == 0 && memcmp(a.lower_left_corner, b.lower_left_corner, sizeof a.lower_left_corner) == 0 &&
+         a.lens_radius == b.lens_radius && a.max_depth == b.max_depth;
+}
+int ensure_cost_order(pt_ctx* c, uint32_t n_frames) {
+  if (c->params.samples_per_pixel < 4) {
+    if (c->order_probed) {  // back to the identity order: the costs are all zero after a probe, and the sort is stable
+      c->order_probed = false;
+      c->tile_order_valid = false;
+    }
+    return ensure_tile_order(c);
+  }
+  const bool fresh = c->order_probed && c->tile_order_valid && c->order_scene_gen == c->scene_gen &&
+                     (same_view(c->order_view, c->params) || c->frames_since_probe < 64u);
+  c->frames_since_probe += n_frames;
+  if (fresh) return PT_OK;
+  int rc = ensure_tile_order(c);
+  if (rc != PT_OK) return rc;
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->stream, &cap);
+    if (cap != hipStreamCaptureStatusNone) return PT_OK;  // (a caller capturing single frames: no probe inside its graph)
+  }
+  Launch L;
+  rc = prepare_launch(c, 1, false, &L);
+  if (rc != PT_OK) return rc;
+  L.A.cost_feedback = 1u;
+  L.A.wave_log = nullptr;
+  L.A.cell_hist = nullptr;
+  L.A.slab = reinterpret_cast<float*>(c->d_slab);  // scratch: a frame's own slab is written before it is read
+  unsigned long long* seg = &c->d_counters[PT_CTR_SEGMENTS];
+  PT_HIP(c, hipMemcpyAsync(&c->d_counters[PT_CTR_SCRATCH], seg, sizeof *seg, hipMemcpyDeviceToDevice, c->stream));
+  if (!L.A.queue_static) PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  {
+    void* kargs[] = {&L.A};
+    PT_HIP(c, hipLaunchKernel(L.kfn, dim3(L.grid), dim3(L.block), kargs, L.lds, c->stream));
+  }
+  hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_tile_cost, c->d_tile_order,
+                     ((c->width + 7) / 8) * ((c->local_rows + 7) / 8));
+  PT_HIP(c, hipGetLastError());
+  PT_HIP(c, hipMemcpyAsync(seg, &c->d_counters[PT_CTR_SCRATCH], sizeof *seg, hipMemcpyDeviceToDevice, c->stream));
+  c->order_probed = true;
+  c->order_view = c->params;
+  c->order_scene_gen = c->scene_gen;
+  c->frames_since_probe = 0;
+  return PT_OK;
+}
+
 int frame_ready(pt_ctx* c, const char* who) {
   if (!c) return PT_ERR_INVALID;
   if (!c->have_spheres || !c->have_params)
@@ -1371,7 +1441,7 @@ PT_API int pt_render_frame(pt_ctx* c, uint32_t even_odd_count) {
   FramePlan F;
   rc = plan_frame(c, c->d_frame_ctr + 1, even_odd_count, 0x7fffffff, 1, c->d_slab, &F);  // frame 0 of a series of one
   if (rc != PT_OK) return rc;
-  rc = ensure_tile_order(c);
+  rc = ensure_cost_order(c, 1);
   if (rc != PT_OK) return rc;
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
   rc = enqueue_frame(c, F, false);
@@ -1423,7 +1493,7 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     counts[g + 1] += counts[g] * (kFrameGroups[g] / kFrameGroups[g + 1]);
     counts[g] = 0;
   }
-  rc = ensure_tile_order(c);  // outside the capture: it runs once, not per frame
+  rc = ensure_cost_order(c, n_frames);  // outside the capture: it runs once per series at most, not per frame
   if (rc != PT_OK) return rc;
   // everything a graph bakes in is decided outside the capture; a cached graph is reused while that is unchanged
   // (pt_set_params with the same values, as a frame loop issues before every series, does not re-capture)

@@ -123,7 +123,7 @@ enum { PT_COH_BINS = 66, PT_HIST_WAVE_STRIDE = 8 };  // cell_hist: bins 0..64 = 
 enum { PT_REG_REFILL_DECODE = 0, PT_REG_REFILL_RESERVE, PT_REG_CAMERA_RAY, PT_REG_SHADE_HIT_RECORD, PT_REG_SHADE_SKY, PT_REG_SHADE_DIFFUSE,
        PT_REG_SHADE_METAL, PT_REG_SHADE_GLASS, PT_REG_SHADE_GLASS_REFRACT, PT_REG_SHADE_CONTINUES, PT_REG_SHADE_FINISHED, PT_REG_SHADE_ITEM_STORE,
        PT_REG_WALK_ENTRY, PT_REG_WALK_ENTER_CELL, PT_REG_WALK_FAR_RAY, PT_REG_SHADE_ANY, PT_N_REGIONS };
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_SCRATCH = 7 /* host-side save / restore of a counter around a probe launch */, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.

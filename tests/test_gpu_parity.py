@@ -1446,3 +1446,34 @@ def test_plain_c_multi_gpu_example_gathers_the_single_gpu_frame(tmp_path, ora):
         assert how in line and "%d segments" % seg in line and "same gathered frame: yes" in line, line
         got = np.fromfile(out, dtype=np.float32).reshape(90, 160, 4)
         assert_bit_equal(got, single, "render_bands with %d rank(s)" % ranks)
+
+
+def test_frames_probe_a_cost_sorted_tile_order_without_a_trace_in_results_or_statistics(ora):
+    """pt_render_frame(s) probe a cost-sorted tile order (one extra pass with the cost feedback on, into scratch) when there is
+    none for the scene and view: scheduling only.  The canvas is the oracle's frame loop, the segment statistics count the
+    frames' own segments and nothing else, and a second series at the same view does not probe again (same counts)."""
+    from ray_tracer_webgl_amd.app import FrameLoop
+
+    w, h, n = 120, 67, 6
+    loop = FrameLoop(w, h, mode="reference")
+    loop.state.set_flags(is_paused=False)
+    loop.tracer.reset()
+    assert loop.frames(n, 100.0, 16.5) == n
+    chk = FrameLoop(w, h, mode="reference")
+    chk.state.set_flags(is_paused=False)
+    tex = [np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 4), np.uint8)]
+    spheres = chk.state.spheres()
+    total = 0
+    for k in range(n):
+        now = 100.0 + 16.5 * k
+        chk.state.update_position(now if k == 0 else 16.5)
+        chk.state.update_render_globals()
+        v, p = chk.state.view(), chk.state.to_params(now)
+        acc, seg = ora.render(spheres, p, 1)
+        total += seg
+        expect = ora.blend_rgba8(acc, p.samples_per_pixel, p, tex[(v.even_odd_count + 1) % 2])
+        tex[v.even_odd_count % 2] = expect
+    assert np.array_equal(loop.canvas, expect)
+    assert loop.tracer.stats().segments == total, (loop.tracer.stats().segments, total)
+    loop.close()
+    chk.close()
