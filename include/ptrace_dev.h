@@ -25,7 +25,8 @@ long pt_debug_wave_log(pt_ctx* ctx, unsigned long long* out, size_t cap_waves);
 /* The grid twins' gather statistics of the last counted launch (every 8th wave sampled): out[0 .. n_entries) = leaf-round
  * lanes per entry-run start (index into the grid's entry array), then 66 values: bins 0..64 = leaf rounds with that many
  * DISTINCT runs among their lanes, [65] = the sampled rounds' lanes.  Returns the number of values written (n_entries + 66
- * when cap allows), < 0 when there is none. */
+ * when cap allows), < 0 when there is none.  The histogram costs the twin several times its run time (atomics, a loop over the
+ * distinct runs of every sampled round), so it is filled only at pt_set_option(ctx, PT_OPT_COUNT_WORK, 2); 1 is the plain twin. */
 long pt_debug_cell_hist(pt_ctx* ctx, uint32_t* out, size_t cap);
 /* Where the set-up calls of this context spent their time, host clock, milliseconds (bench.py's `first_frame`):
  * pt_create: the process's first HIP call (runtime start; ~0 in a process that has used HIP before), device selection
