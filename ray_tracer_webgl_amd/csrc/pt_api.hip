@@ -489,7 +489,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     mat[i].refraction_index = s[i].refraction_index;
     mat[i].type = s[i].type;
     mat[i].radius = s[i].radius;
-    mat[i].uuid = s[i].uuid;
+    mat[i].inv_ri = 1.0f / s[i].refraction_index;  // (IEEE division, -ffp-contract=off: what `1.0 / ri` is in the shader's arithmetic contract)
     radii[i] = s[i].radius;
   }
   const double t_split = host_ms();

@@ -11,10 +11,10 @@ struct PtMatRec {
   float refraction_index;
   int32_t type;
   float radius;  // signed: the outward normal divides by it (static/shader.frag:170)
-  int32_t uuid;
+  float inv_ri;  // 1.0f / refraction_index, the IEEE quotient made once on the host: GLASS divides by the index whenever the
+                 // ray enters (static/shader.frag:252), and a correctly rounded fp32 division is the same bits wherever it is done
 };
 static_assert(sizeof(PtMatRec) == 32, "PtMatRec must be 32 bytes");
-
 // Exact division of a 32-bit n by a launch-invariant d without a divide (Granlund & Montgomery):
 // q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n).  The constants are made on the host so
 // that they arrive in SGPRs; a wave-uniform division done in the kernel would be hoisted out

@@ -38,7 +38,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
   // the seed moves only for the lanes that draw): State::default -1.4 %, config 5 -0.6 %, configs 2 and 4 +-0.1 %
   // (profiles/r04_ab_runs.txt).
   int mtype = -1;
-  V3 hp = mk(0.f, 0.f, 0.f), n = hp, alb = hp; bool front = false; float fuzz = 0.f, ri = 1.f;
+  V3 hp = mk(0.f, 0.f, 0.f), n = hp, alb = hp; bool front = false; float fuzz = 0.f, ri = 1.f, inv_ri = 1.f;
   if (hit >= 0) {
     tally.flag(PT_REG_SHADE_HIT_RECORD);
     float4 g;
@@ -53,10 +53,10 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       if (hit_pos != 0xffffffffu) mp = reinterpret_cast<const float4*>(A.slot_mat + hit_pos);
     }
     float4 m0 = mp[0]; // albedo.xyz, fuzz
-    float4 m1 = mp[1]; // refraction_index, type, radius, uuid
+    float4 m1 = mp[1]; // refraction_index, type, radius, 1 / refraction_index
     mtype = __float_as_int(m1.y);
     float radius = m1.z;
-    fuzz = m0.w; ri = m1.x;
+    fuzz = m0.w; ri = m1.x; inv_ri = m1.w;
     hp = mk(fma_(d.x, closest, o.x), fma_(d.y, closest, o.y), fma_(d.z, closest, o.z)); // hit record, :166-171
     const float nx = hp.x - g.x, ny = hp.y - g.y, nz = hp.z - g.z; // outward normal (p - centre) / radius, :168 (see above)
     V3 on;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       }
     } else if (mtype == 2) { // GLASS :250-282
       tally.flag(PT_REG_SHADE_GLASS);
-      float ratio = front ? (1.0f / ri) : ri;
+      float ratio = front ? inv_ri : ri;  // :252 `1.0 / ri`: the host's quotient, same bits as the division here (pt_kernel_args.h)
       V3 ud = mk(d.x * inv, d.y * inv, d.z * inv);
       float cdot = dot3(mk(-ud.x, -ud.y, -ud.z), n);
       float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
