@@ -139,6 +139,14 @@ struct pt_ctx {
 
 namespace {
 
+// the work queue's heads start a launch at zero: the shared head, or the grouped queue's (pt_refill.hpp)
+inline hipError_t zero_queue_heads(pt_ctx* c, uint32_t queue_static) {
+  if (queue_static == 2u)
+    return hipMemsetAsync(&c->d_counters[PT_CTR_GROUP_HEADS], 0, 8 * PT_QUEUE_GROUPS_MAX * sizeof(unsigned long long), c->stream);
+  if (queue_static == 0u) return hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream);
+  return hipSuccess;
+}
+
 inline double host_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -359,10 +367,10 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
     return bail(e, "hipStreamCreateWithFlags");
   c->stream = c->own_stream;
   const double t_stream = host_ms();
-  if ((e = hipMalloc(&c->d_counters, PT_CTR_COUNT * sizeof(unsigned long long))) != hipSuccess)
+  if ((e = hipMalloc(&c->d_counters, PT_CTR_ALLOC * sizeof(unsigned long long))) != hipSuccess)
     return bail(e, "hipMalloc(counters)");
   const double t_first_malloc = host_ms();
-  if ((e = hipMemsetAsync(c->d_counters, 0, PT_CTR_COUNT * sizeof(unsigned long long), c->stream)) != hipSuccess)
+  if ((e = hipMemsetAsync(c->d_counters, 0, PT_CTR_ALLOC * sizeof(unsigned long long), c->stream)) != hipSuccess)
     return bail(e, "hipMemsetAsync(counters)");
   const double t_first_memset = host_ms();
   if ((e = hipMalloc(&c->d_frame_ctr, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(frame counter)");
@@ -1140,6 +1148,30 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
     }
   }
 
+  // ... and between the two lies the GROUPED queue (round 5; pt_refill.hpp): G groups of waves, each with a head of its own,
+  // wave w in group w % G, group g owning the reservations g, g + G, ... — a queue's balance among a group's ~28 waves at one
+  // atomic per reservation on one of G = 256 addresses.  It replaces the static deal from 16 SAMPLES per lane on: below that
+  // a wave takes so few reservations that the atomic's round trip, which finds the whole wave idle (all lanes of a
+  // short-item launch run dry together), costs more than the balance gives.  Measured static / grouped, ms
+  // (profiles/r05_ab_runs.txt): the reference's scene 16 x 1 spp 0.579 / 0.533, groups of 1- / 2-spp frames 0.0384 / 0.0351 and
+  // 0.0697 / 0.0598 per frame, 8 spp x 4 0.958 / 0.889, cover scene 16 x 1 spp 2.93 / 2.55, 4 spp x 2 1.62 / 1.41; but 4 x 1 spp
+  // 0.164 / 0.203, the single 1-spp frame 0.079 / 0.088, the single 4-spp frame 0.172 / 0.186.  G is the largest power of
+  // two that is neither above the CU count nor above the launch's wave count (every group needs a wave: nobody else hands
+  // out its reservations).
+  if (A.queue_static) {
+    const unsigned long long lanes_now = (unsigned long long)A.n_waves * 64ull;
+    bool grouped = items * spp_u >= 16ull * lanes_now;
+#ifdef PT_DEV_KNOBS
+    if (const char* e = getenv("PT_QUEUE_GROUPED")) grouped = atoi(e) != 0;
+#endif
+    if (grouped) {
+      uint32_t g = 1u;
+      while (2u * g <= (uint32_t)c->num_cus && 2u * g <= (uint32_t)PT_QUEUE_GROUPS_MAX && 2u * g <= A.n_waves) g *= 2u;
+      A.queue_groups = g;
+      A.queue_static = 2u;
+    }
+  }
+
   L->kfn = kfn; L->grid = grid; L->block = block; L->lds = lds; L->path = path; L->trial = trial;
   return PT_OK;
 }
@@ -1217,8 +1249,7 @@ PT_API int pt_render_passes(pt_ctx* c, uint32_t n_passes) {
   }
   std::pair<hipEvent_t, hipEvent_t>* ev = capturing ? nullptr : &c->events[c->events_used++];
 
-  if (!A.queue_static)  // (a statically dealt launch takes no reservations from the shared head)
-    PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  PT_HIP(c, zero_queue_heads(c, A.queue_static));  // (a statically dealt launch takes no reservations from any head)
   // queue order from the previous launch's per-tile cost (identity when there is none yet); launches
   // that report no cost keep the order they find
   if (A.cost_feedback || !c->tile_order_valid) {
@@ -1334,7 +1365,7 @@ int enqueue_frame(pt_ctx* c, FramePlan& F, bool advance) {
     PT_HIP(c, hipGetLastError());
   }
   if (advance) {
-    hipLaunchKernelGGL(pt_frame_advance_kernel, dim3(1), dim3(64), 0, c->stream, c->d_frame_ctr, &c->d_counters[PT_CTR_HEAD], F.n_frames);
+    hipLaunchKernelGGL(pt_frame_advance_kernel, dim3(1), dim3(PT_QUEUE_GROUPS_MAX), 0, c->stream, c->d_frame_ctr, c->d_counters, F.n_frames);
     PT_HIP(c, hipGetLastError());
   }
   return PT_OK;
@@ -1397,7 +1428,7 @@ int ensure_cost_order(pt_ctx* c, uint32_t n_frames) {
   L.A.slab = reinterpret_cast<float*>(c->d_slab);  // scratch: a frame's own slab is written before it is read
   unsigned long long* seg = &c->d_counters[PT_CTR_SEGMENTS];
   PT_HIP(c, hipMemcpyAsync(&c->d_counters[PT_CTR_SCRATCH], seg, sizeof *seg, hipMemcpyDeviceToDevice, c->stream));
-  if (!L.A.queue_static) PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  PT_HIP(c, zero_queue_heads(c, L.A.queue_static));
   {
     void* kargs[] = {&L.A};
     PT_HIP(c, hipLaunchKernel(L.kfn, dim3(L.grid), dim3(L.block), kargs, L.lds, c->stream));
@@ -1444,6 +1475,7 @@ PT_API int pt_render_frame(pt_ctx* c, uint32_t even_odd_count) {
   rc = ensure_cost_order(c, 1);
   if (rc != PT_OK) return rc;
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  PT_HIP(c, zero_queue_heads(c, 2u));
   rc = enqueue_frame(c, F, false);
   if (rc != PT_OK) return rc;
   c->launches++;
@@ -1523,6 +1555,7 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
   // the series starts at frame 0 with an empty queue; every replay leaves both ready for the next
   PT_HIP(c, hipMemsetAsync(c->d_frame_ctr, 0, sizeof(uint32_t), c->stream));
   PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
+  PT_HIP(c, zero_queue_heads(c, 2u));
   if (c->events_used == c->events.size()) {
     if (c->events.size() >= 512) {
       PT_HIP(c, hipStreamSynchronize(c->stream));

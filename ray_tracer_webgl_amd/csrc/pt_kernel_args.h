@@ -83,7 +83,10 @@ struct PtKernelArgs {
   uint32_t coop_max_live;          // tail mode when at most this many lanes of a wave hold a ray
   int32_t rr_min_depth;            // Russian roulette after this many bounces (0 = never: the reference's estimator)
   uint32_t lens_off;               // 1: lens_radius is 0, u and v are finite, no component of the origin is -0 (pt_refill.hpp start_sample)
-  uint32_t queue_static;           // 1: no queue atomics — wave w takes the reservations w, w + n_waves, w + 2 n_waves, ...
+  uint32_t queue_groups;           // queue_static == 2: the number of wave groups G (a power of two), each with a head of its own
+  uint32_t queue_static;           // 2: GROUPED queue — wave w belongs to group w % G and takes the group's reservations g, g + G, g + 2 G, ...
+                                   // in the order its group's head hands them out (one atomic per reservation on one of G addresses);
+                                   // 1: no queue atomics — wave w takes the reservations w, w + n_waves, w + 2 n_waves, ...
                                    // (launches of a few items per lane: every reservation of the shared queue is an atomic
                                    // on ONE address, ~25 ns each in turn; 28 000 of them ARE the 1-spp frame's 0.78 ms)
   uint32_t n_waves;                // waves of the launch (grid x workgroup / 64)
@@ -123,7 +126,9 @@ enum { PT_COH_BINS = 66, PT_HIST_WAVE_STRIDE = 8 };  // cell_hist: bins 0..64 = 
 enum { PT_REG_REFILL_DECODE = 0, PT_REG_REFILL_RESERVE, PT_REG_CAMERA_RAY, PT_REG_SHADE_HIT_RECORD, PT_REG_SHADE_SKY, PT_REG_SHADE_DIFFUSE,
        PT_REG_SHADE_METAL, PT_REG_SHADE_GLASS, PT_REG_SHADE_GLASS_REFRACT, PT_REG_SHADE_CONTINUES, PT_REG_SHADE_FINISHED, PT_REG_SHADE_ITEM_STORE,
        PT_REG_WALK_ENTRY, PT_REG_WALK_ENTER_CELL, PT_REG_WALK_FAR_RAY, PT_REG_SHADE_ANY, PT_N_REGIONS };
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_SCRATCH = 7 /* host-side save / restore of a counter around a probe launch */, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128 };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_SCRATCH = 7 /* host-side save / restore of a counter around a probe launch */, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128,
+       PT_QUEUE_GROUPS_MAX = 256, PT_CTR_GROUP_HEADS = 128 /* then PT_QUEUE_GROUPS_MAX heads, 8 u64 (one 64-byte line) apart */,
+       PT_CTR_ALLOC = PT_CTR_GROUP_HEADS + 8 * PT_QUEUE_GROUPS_MAX };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 
 // Largest sphere list one workgroup can stage: 160 KiB LDS / 16 B (MI355X_MICROARCH.md §LDS);
 // the staged list is padded to a multiple of 8 (two ping-pong groups of 4) plus one prefetch group.

@@ -315,11 +315,13 @@ extern "C" __global__ __launch_bounds__(256) void pt_frames_blend_kernel(
 }
 
 // end of a replay of n frames: the next one starts at frame k + n, and its work queue at item 0
-extern "C" __global__ void pt_frame_advance_kernel(uint32_t* ctr, unsigned long long* queue_head, uint32_t n) {
+extern "C" __global__ void pt_frame_advance_kernel(uint32_t* ctr, unsigned long long* counters, uint32_t n) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctr[0] += n;
-    queue_head[0] = 0ull;
+    counters[PT_CTR_HEAD] = 0ull;
   }
+  // (the grouped queue's heads: launched with PT_QUEUE_GROUPS_MAX threads)
+  if (blockIdx.x == 0 && threadIdx.x < PT_QUEUE_GROUPS_MAX) counters[PT_CTR_GROUP_HEADS + 8u * threadIdx.x] = 0ull;
 }
 
 // --------------------------------------------------------------------------------------------

@@ -123,9 +123,20 @@ __device__ __forceinline__ void refill(const PtKernelArgs& A, Path& p, Queue& q,
     if (pool_next == pool_end) { // wave-uniform
       tally.flag(PT_REG_REFILL_RESERVE);
       unsigned long long base = 0;
-      if (K.queue_static != 0u) {
-        // short launches: reservations are dealt round-robin, no atomics (a wave's number is the same in
-        // all its lanes)
+      if (K.queue_static == 2u) {
+        // GROUPED queue (short launches): the waves form G groups, group g owns the reservations g, g + G, g + 2 G, ... of the
+        // tile-major list and hands them to its waves in the order they ask — the balance of a queue among a group's ~28 waves
+        // with one atomic per reservation on one of G addresses (the single head of the shared queue takes a reservation
+        // every ~13 ns: too slow for items of a few segments; no atomics at all — static dealing — leaves every wave
+        // alone with the cost of the ~31 tiles it happens to get)
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const uint32_t group = wave & (K.queue_groups - 1u);
+        unsigned long long r = 0;
+        if (lane_id() == 0u) r = atomicAdd(&A.counters[PT_CTR_GROUP_HEADS + 8u * group], 1ull);
+        const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+        base = ((unsigned long long)r_lo * K.queue_groups + group) * (unsigned long long)A.queue_chunk;
+      } else if (K.queue_static != 0u) {
+        // reservations dealt round-robin, no atomics (a wave's number is the same in all its lanes)
         const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         base = ((unsigned long long)q_round * K.n_waves + wave) * (unsigned long long)A.queue_chunk;
         q_round++;
