@@ -1115,7 +1115,11 @@ static int prepare_launch(pt_ctx* c, uint32_t n_passes, bool allow_trials, Launc
   const unsigned long long lanes_all = (unsigned long long)A.n_waves * 64ull;
   const unsigned long long spp_u = (unsigned long long)(c->params.samples_per_pixel > 0 ? c->params.samples_per_pixel : 1);
   const bool short_items = c->params.samples_per_pixel <= 2 && items < 64ull * lanes_all;
-  A.queue_static = (short_items || items * spp_u < 112ull * lanes_all) ? 1u : 0u;
+  // (round 5, with the GROUPED queue below taking the statically dealt launches from 16 samples per lane on: the shared queue
+  // only wins from ~450 samples per lane — grouped / shared: 25 spp x 4 (196) 2.52 / 2.61, 64 spp x 2 (250) 3.21 / 3.42, cover
+  // scene 16 spp x 2 (169) 4.47 / 4.70, x 4 (337) 8.04 / 8.31, but x 8 (674) 15.25 / 14.69 and the full frame 120.8 / 110.0:
+  // long launches want the shared queue's big reservations and its balance across ALL waves)
+  A.queue_static = (short_items || items * spp_u < 448ull * lanes_all) ? 1u : 0u;
 #ifdef PT_DEV_KNOBS
   if (const char* e = getenv("PT_QUEUE_STATIC")) A.queue_static = atoi(e) ? 1u : 0u;
   if (const char* e = getenv("PT_COST_FEEDBACK")) A.cost_feedback = atoi(e) ? 1u : 0u;
