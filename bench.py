@@ -321,7 +321,7 @@ def main():
     ap.add_argument("--no-weak-series", action="store_true", help="N > 1: skip the weak-scaling point after the main region")
     ap.add_argument("--cpu-strip", type=int, default=None,
                     help="width of the CPU baseline's column strip (default per config: 10-30 s of CPU work)")
-    ap.add_argument("--frames", type=int, default=400, help="--config default: frames per timed replay series")
+    ap.add_argument("--frames", type=int, default=640, help="--config default: frames per timed replay series (640 = ten groups of 64)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="--config default: only the replayed animation loop (no host-issued ticks, no paused 25-spp frames): what profiles/collect.sh runs under the PMC passes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -844,7 +844,7 @@ def frame_loop_bench(args):
     app.FrameLoop's "reference" mode, with the per-frame work (trace + fold + blend) replayed from
     hipGraphs.  A step is one frame; `value` is frames per second, with Mray/s beside it; the
     25-spp paused mode (src/webgl.rs:342-346) is timed beside it.  Like the main line it carries
-    `roofline` (the trace launch of one group of 16 frames: pt_trace_kernel_small_t1, a LIST kernel, so
+    `roofline` (the trace launch of one group of 64 frames: pt_trace_kernel_small_t1, a LIST kernel, so
     executed work = algorithmic work) and `cpu_baseline` (the oracle replaying the same ticks: one
     1-spp pass + the shader's blend per tick, on this host's cores)."""
     from ray_tracer_webgl_amd.app import frame_loop_benchmark

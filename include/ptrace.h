@@ -290,7 +290,7 @@ int pt_blend_rgba8(pt_ctx* ctx, const uint8_t* prev_rgba8, uint8_t* out_rgba8);
  * should_average / last_frame_weight, draw the result to the canvas and, when should_average, to
  * texture[even_odd_count % 2].  Asynchronous on the context's stream; nothing crosses PCIe.
  * pt_render_frames replays n_frames ticks at a constant frame interval from captured hipGraphs —
- * groups of 16 and of 4 frames (ONE trace launch renders a group's frames as its passes into slabs of
+ * groups of 64 (while their slabs stay below 1 GiB), 16 and 4 frames (ONE trace launch renders a group's frames as its passes into slabs of
  * their own, allocated by the first call that needs them; their blends follow in order; advance) and
  * single frames for the remainder (trace + blend + advance) — with the per-frame
  * state of State::update_render_globals (src/state.rs:443-450) kept on the device: frame k of the

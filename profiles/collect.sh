@@ -41,7 +41,7 @@ for CFG in ${PT_COLLECT_CONFIGS-3 4 5 default}; do  # (PT_COLLECT_CONFIGS="" col
   BC="python3 bench.py --config $CFG --no-cpu-baseline --no-work-count --no-list-walk --no-first-frame"
   # the reference's own operating point: only the replayed animation loop + the group's trace launch on its own
   # (the longest pt_trace_kernel_small_t1 dispatches are then the groups of 16 frames, which summarize.py keeps)
-  if [ "$CFG" = "default" ]; then BC="python3 bench.py --config default --no-cpu-baseline --no-extra-legs --frames 400"; fi
+  if [ "$CFG" = "default" ]; then BC="python3 bench.py --config default --no-cpu-baseline --no-extra-legs --frames 640"; fi
   timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OC/kt -- $BC > $OC/kt.log 2>&1
   i=0
   for grp in \

@@ -7,7 +7,7 @@ run_setters -> render -> (save).  Two display modes:
     textures (src/webgl.rs:186-204) — the reference's on-screen behaviour, 8-bit quantisation
     and gamma-space averaging included.  The textures live on the device (pt_render_frame); a run
     of ticks at a constant frame interval is replayed from hipGraphs (`frames`, pt_render_frames:
-    groups of 16 and 4 frames, each traced by one launch) with the per-frame state counted on the device.
+    groups of 64, 16 and 4 frames, each traced by one launch) with the per-frame state counted on the device.
   * "linear": passes accumulate as fp32 linear radiance (north_star's "accumulated radiance")
     and are resolved at read-out; a camera change (render_count reset to 0,
     src/state.rs:343-346) clears the accumulation.
@@ -114,7 +114,7 @@ class FrameLoop:
 def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device=0, extra_legs=True):
     """bench.py --config default: the reference at its own operating point (State::default, 9 spheres,
     1280x702 = images/14.png, depth 8; src/state.rs:127-135).  Times (i) the animation loop — 1 spp per
-    tick, blended into the RGBA8 textures, replayed from hipGraphs in groups of 16 — and (ii) the 25-spp frames the
+    tick, blended into the RGBA8 textures, replayed from hipGraphs in groups of 64 — and (ii) the 25-spp frames the
     reference draws while paused (src/webgl.rs:342-346), plus (iii) the same ticks issued one by one
     from the host (uniform upload + three launches per frame) for comparison.  Returns the JSON dict."""
     from . import abi
@@ -125,7 +125,7 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
     n_sph = st.view().n_spheres
 
     def run(kind, n):
-        """kind: "graph" = the animation loop replayed from hipGraphs (groups of 16 and 4 frames); "host" = the same ticks issued one
+        """kind: "graph" = the animation loop replayed from hipGraphs (groups of 64, 16 and 4 frames); "host" = the same ticks issued one
         by one; "paused" = what the reference draws while paused: ONE 25-spp frame after every camera
         change (render_count == 0, src/lib.rs:77-82, src/webgl.rs:342-346) — here after a yaw nudge"""
         paused = kind == "paused"
@@ -142,7 +142,7 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
                         st.set_camera_angles(-90.0 + 0.25 * (1 + (k & 1)), 0.0)  # a camera change: render_count = 0
                     assert loop.frame(now0 + dt * k)
 
-        ticks(0, max(1, warmup))  # first capture, tile order, clocks
+        ticks(0, max(85 if kind == "graph" else 1, warmup))  # first capture of every group size (64 + 16 + 4 + 1), tile order, clocks
         loop.tracer.synchronize()
         loop.tracer.reset()
         t0 = time.perf_counter()
@@ -159,7 +159,7 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
             "segments_per_frame": round(s.segments / n, 1),
             "device_ms_per_frame": round(s.render_kernel_ms / n, 4) if kind == "graph" else None,
             "geometry_path": abi.GEOM_NAMES.get(s.geometry_path, "?"),
-            "how": {"graph": "%d frames replayed from hipGraphs in groups of 16 and 4 (one trace launch renders a group's frames as its passes, one "
+            "how": {"graph": "%d frames replayed from hipGraphs in groups of 64, 16 and 4 (one trace launch renders a group's frames as its passes, one "
                              "kernel runs their blends, one advance), per-frame state on the device" % n,
                     "host": "uniform upload + trace + blend issued per frame from the host",
                     "paused": "one frame per camera change, issued from the host (uniform upload + trace + blend)"}[kind],
@@ -170,10 +170,10 @@ def frame_loop_benchmark(n_frames=400, warmup=16, width=1280, height=702, device
     paused = run("paused", max(8, n_frames // 8)) if extra_legs else None
     st.set_flags(is_paused=False)
     canvas = loop.canvas
-    # The dominant kernel of the animation loop on its own: the trace launch of one GROUP of 16 frames (16 passes of 1 spp,
+    # The dominant kernel of the animation loop on its own: the trace launch of one GROUP of 64 frames (64 passes of 1 spp,
     # pass k at u_time = now + k * interval, exactly the launch pt_render_frames captures), timed with HIP events on the
     # launch stream around that kernel alone (PtStats.render_kernel_ms) — what bench.py's `roofline` prices.
-    group = 16
+    group = 64
     p = st.to_params(3000.0)
     p.time_step, p.first_pass = 16.7, 0
     loop.tracer.set_params(p)

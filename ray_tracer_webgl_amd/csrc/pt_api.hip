@@ -115,10 +115,10 @@ struct pt_ctx {
   uint32_t* d_canvas = nullptr;
   size_t tex_pixels = 0;
   uint32_t* d_frame_ctr = nullptr;
-  // captured frames, one graph per group size (kFrameGroups: 16, 4, 1 frames — a group is ONE trace launch of that many passes,
+  // captured frames, one graph per group size (kFrameGroups: 64, 16, 4, 1 frames — a group is ONE trace launch of that many passes,
   // one kernel for their blends, one advance; a single frame is trace + blend + advance), each captured once per plan
-  hipGraphExec_t frame_exec[3] = {nullptr, nullptr, nullptr};
-  unsigned char frame_plan[3][1024] = {{0}, {0}, {0}};  // the FramePlan each cached graph was captured from (compared bytewise)
+  hipGraphExec_t frame_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned char frame_plan[4][1024] = {{0}, {0}, {0}, {0}};  // the FramePlan each cached graph was captured from (compared bytewise)
   float4* d_frame_slab = nullptr;        // a group's slabs (up to 16 passes), allocated by the first pt_render_frames that needs them
   size_t frame_slab_pixels = 0;
   uint64_t epoch = 0;                    // bumped by everything a captured frame bakes in
@@ -173,7 +173,19 @@ int fail(pt_ctx* c, int code, const char* fmt, ...) {
 // per graph -> 8 190 / 12 690 / 18 960 / 21 040 / 21 790 / 21 000 frames per second)
 // 960 frames with the group's blends as one kernel: 8 / 12 / 16 / 24 per graph -> 22 640 / 23 020 / 23 940 / 24 250; 16 it is (230 MB of slabs
 // at that size), with groups of 4 and single frames for what is left of a series
-constexpr uint32_t kFrameGroups[3] = {16u, 4u, 1u};
+// frames per replayed graph, largest first.  Round 4 (separate blends, static deal): 1 / 2 / 4 / 8 / 16 / 32 frames -> 8 190 ... 21 790 /
+// 21 000 frames per second, hence 16.  Round 5, with the group's launch dealt through the grouped queue and every wave resident
+// (bench.py --config default, 1 920 frames): 16 / 24 / 32 / 48 / 64 frames per group -> 28 530 / 29 880 / 30 930 / 31 760 / 32 020:
+// a longer launch amortises its start and drain, hence 64 — while its slabs stay below kFrameSlabCap (64 x 1280 x 702 x 16 B =
+// 0.92 GB; a 1920x1080 series uses groups of 16: 0.53 GB)
+constexpr int kFrameLevels = 4;
+#ifdef PT_DEV_KNOBS
+static uint32_t kFrameGroups[kFrameLevels] = {64u, 16u, 4u, 1u};
+struct FrameGroupKnob { FrameGroupKnob() { if (const char* e = getenv("PT_FRAME_GROUP")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 16u && v <= 128u && v % 16u == 0u) kFrameGroups[0] = v; } } } g_frame_group_knob;
+#else
+constexpr uint32_t kFrameGroups[kFrameLevels] = {64u, 16u, 4u, 1u};
+#endif
+constexpr size_t kFrameSlabCap = (size_t)1 << 30;  // bytes a group's slabs may take
 
 uint32_t count_local_rows(uint32_t height, const PtParams& p) {
   return pt_local_rows(height, p.band_rows, p.band_index, p.band_count);
@@ -1503,20 +1515,24 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     return fail(c, PT_ERR_INVALID, "pt_render_frames: the context runs on the legacy default stream (PT_STREAM_LEGACY), which cannot be "
                                    "captured into a hipGraph; give it a stream of its own (pt_set_stream(ctx, NULL) or a created stream) "
                                    "or issue the ticks with pt_render_frame");
-  // Frames in GROUPS of 16 and 4: ONE trace launch renders a group's frames as its passes (each pass has its own u_time: the
+  // Frames in GROUPS of 64, 16 and 4: ONE trace launch renders a group's frames as its passes (each pass has its own u_time: the
   // frame's), one kernel runs their blends in order.  A 1-spp frame of the reference's size is two items per resident lane,
   // and a wave ends when its slowest lane does: most of a single frame's 0.11 ms is that drain; a group shares one.  What is
   // left of the series is replayed frame by frame.  Same bits either way: a frame is a pass.
-  uint32_t counts[3] = {0, 0, 0};
+  uint32_t counts[kFrameLevels] = {0, 0, 0, 0};
   {
     uint32_t left = n_frames;
-    for (int g = 0; g < 3; g++) { counts[g] = left / kFrameGroups[g]; left -= counts[g] * kFrameGroups[g]; }
+    for (int g = 0; g < kFrameLevels; g++) {
+      if (kFrameGroups[g] > 16u && (size_t)c->local_rows * c->width * kFrameGroups[g] * sizeof(float4) > kFrameSlabCap) continue;  // (too big a slab)
+      counts[g] = left / kFrameGroups[g];
+      left -= counts[g] * kFrameGroups[g];
+    }
   }
   // the groups' own slabs (never the slab of pt_render_passes: a caller's captured launches keep theirs): the one allocation
   // this entry point ever makes, at the first use of a size.  16 x local_rows x width x 16 B is 230 MB at the reference's
   // 1280x702 and 2.1 GB at 4K; when it cannot be had the series falls back to groups of 4 (a quarter of it) and then to
   // single frames out of the slab every context owns — slower, never a failed call.
-  for (int g = 0; g < 2; g++) {
+  for (int g = 0; g < kFrameLevels - 1; g++) {
     if (!counts[g]) continue;
     const size_t need = (size_t)c->local_rows * c->width * kFrameGroups[g];
     if (c->frame_slab_pixels >= need) break;
@@ -1554,7 +1570,7 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
     memcpy(static_cast<void*>(plan_store), &F, sizeof F);
     return PT_OK;
   };
-  for (int g = 0; g < 3; g++)
+  for (int g = 0; g < kFrameLevels; g++)
     if (counts[g]) { rc = graph_for(g); if (rc != PT_OK) return rc; }
   // the series starts at frame 0 with an empty queue; every replay leaves both ready for the next
   PT_HIP(c, hipMemsetAsync(c->d_frame_ctr, 0, sizeof(uint32_t), c->stream));
@@ -1574,7 +1590,7 @@ PT_API int pt_render_frames(pt_ctx* c, uint32_t even_odd_count, uint32_t max_ren
   }
   std::pair<hipEvent_t, hipEvent_t>& ev = c->events[c->events_used++];
   PT_HIP(c, hipEventRecord(ev.first, c->stream));
-  for (int g = 0; g < 3; g++)
+  for (int g = 0; g < kFrameLevels; g++)
     for (uint32_t k = 0; k < counts[g]; k++) PT_HIP(c, hipGraphLaunch(c->frame_exec[g], c->stream));
   PT_HIP(c, hipEventRecord(ev.second, c->stream));
   c->launches += n_frames;

@@ -173,7 +173,7 @@ class PathTracer:
         self._check(self.lib.pt_render_frame(self._ctx, int(even_odd_count) & 0xFFFFFFFF))
 
     def render_frames(self, even_odd_count, max_render_count, n_frames):
-        """n ticks at the constant frame interval params.time_step, replayed from hipGraphs (groups of 16 and 4 frames, then singles) with
+        """n ticks at the constant frame interval params.time_step, replayed from hipGraphs (groups of 64, 16 and 4 frames, then singles) with
         the per-frame state (u_time, render_count, even/odd) counted on the device."""
         self._check(self.lib.pt_render_frames(self._ctx, int(even_odd_count) & 0xFFFFFFFF, int(max_render_count), int(n_frames)))
 

@@ -1477,3 +1477,25 @@ def test_frames_probe_a_cost_sorted_tile_order_without_a_trace_in_results_or_sta
     assert loop.tracer.stats().segments == total, (loop.tracer.stats().segments, total)
     loop.close()
     chk.close()
+
+
+def test_a_series_with_a_group_of_64_frames_matches_single_ticks():
+    """pt_render_frames replays the largest groups first: 85 frames = one group of 64 (ONE trace launch of 64 passes, one
+    blend kernel), one of 16, one of 4 and a single frame.  Canvas and both textures must be those of 85 ticks issued
+    one by one (pt_render_frame, itself checked against the oracle's frame loop above)."""
+    from ray_tracer_webgl_amd.app import FrameLoop
+
+    w, h, n = 72, 40, 85
+    a = FrameLoop(w, h, mode="reference")
+    a.state.set_flags(is_paused=False)
+    for k in range(n):
+        assert a.frame(100.0 + 16.5 * k) is True
+    b = FrameLoop(w, h, mode="reference")
+    b.state.set_flags(is_paused=False)
+    assert b.frames(n, 100.0, 16.5) == n
+    assert np.array_equal(a.canvas, b.canvas)
+    for ta, tb in zip(a.textures, b.textures):
+        assert np.array_equal(ta, tb)
+    assert a.tracer.stats().segments == b.tracer.stats().segments
+    a.close()
+    b.close()

@@ -316,16 +316,16 @@ def test_the_dev_tools_watchdog_polls_instead_of_blocking():
 def test_bench_line_of_the_references_own_operating_point():
     """`bench.py --config default` (State::default, 1280x702, 1 spp per tick, the shader's
     temporal blend: src/state.rs:127-135, src/webgl.rs:180-205) is under the measurement contract like the main
-    line: `roofline` prices the trace launch of one group of 16 frames (a list kernel: executed = algorithmic),
+    line: `roofline` prices the trace launch of one group of 64 frames (a list kernel: executed = algorithmic),
     timed with HIP events around that kernel alone, and `cpu_baseline` is the oracle replaying the same ticks."""
     d = _bench("--config", "default", "--frames", "96", "--warmup", "16")
     assert d["unit"] == "frames/s" and d["value"] > 1000 and d["config"]["workload"].startswith("default: State::default")
     r = d["roofline"]
-    assert r["kernel"] == "pt_trace_kernel_small_t1" and r["passes_per_launch"] == 16 and r["spp_per_pass"] == 1
+    assert r["kernel"] == "pt_trace_kernel_small_t1" and r["passes_per_launch"] == 64 and r["spp_per_pass"] == 1
     assert r["avg_launch_ms"] > 0 and r["launches"] >= 8 and 0 < r["frac"] <= 1 and r["bound"] == "valu"
     # the group's trace launch is most of a group's device time (trace + blend + advance)
-    assert r["avg_launch_ms"] <= 16 * d["animation"]["device_ms_per_frame"] * 1.05
-    assert abs(r["segments_per_launch"] / 16 / d["animation"]["segments_per_frame"] - 1) < 0.01
+    assert r["avg_launch_ms"] <= 64 * d["animation"]["device_ms_per_frame"] * 1.05
+    assert abs(r["segments_per_launch"] / 64 / d["animation"]["segments_per_frame"] - 1) < 0.01
     c = d["cpu_baseline"]
     assert c["unit"] == "frames/s" and c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and "frames" in c["sample"]
     assert d["gpu_over_cpu"] > 10
