@@ -127,15 +127,22 @@ def test_structure(name):
     assert g["delta_g"] >= dk and g["delta_g"] >= delta_of(float(g["rmin"]), float(g["rmax"]), float(g["d_near"]))
     # ... and is not absurd next to a cell
     assert g["delta_g"] < 0.6 * float(g["h"].min()) or name in ("clumps",) or name.endswith("_far")
-    # registration: a sphere is an entry of EVERY cell its box inflated by delta_g touches
+    # registration: a sphere is an entry of EVERY cell its box inflated by ITS delta touches: the kernel's bound with the
+    # sphere's own radius in the square root (sqrt(r^2 + x) - r decreases with r) + what delta_g carries beyond that term
+    # (16 u rmax and the walk's rounding, eps_dda); at r = rmin that is delta_g itself
+    x40 = 40.0 * U * float(g["d_near"]) ** 2
+    dg_walk = float(g["delta_g"]) - (np.sqrt(float(g["rmin"]) ** 2 + x40) - float(g["rmin"]))
+    assert dg_walk >= 16.0 * U * float(g["rmax"])
+    delta_i = np.minimum(float(g["delta_g"]), np.sqrt(r * r + x40) - r + dg_walk)
+    assert np.all(delta_i[gridded] >= np.sqrt(r[gridded] ** 2 + x40) - r[gridded] + 16.0 * U * float(g["rmax"]) - 1e-12)
     lo, h, nn = g["lo"].astype(np.float64), g["h"].astype(np.float64), g["n"]
     member = {}
     for cell in np.nonzero(count)[0]:
         member[int(cell)] = set(index[first[cell]:first[cell] + count[cell]].tolist())
     rng = np.random.default_rng(0)
     for i in rng.choice(gridded, min(len(gridded), 400), replace=False):
-        a = np.clip(np.floor((c[i] - r[i] - float(g["delta_g"]) - lo) / h), 0, nn - 1).astype(np.int64)
-        b = np.clip(np.floor((c[i] + r[i] + float(g["delta_g"]) - lo) / h), 0, nn - 1).astype(np.int64)
+        a = np.clip(np.floor((c[i] - r[i] - delta_i[i] - lo) / h), 0, nn - 1).astype(np.int64)
+        b = np.clip(np.floor((c[i] + r[i] + delta_i[i] - lo) / h), 0, nn - 1).astype(np.int64)
         for z in range(a[2], b[2] + 1):
             for y in range(a[1], b[1] + 1):
                 for x in range(a[0], b[0] + 1):
@@ -353,6 +360,57 @@ def test_walk_returns_the_pair_hit_world_returns(name):
     if len(sph) >= 100 and name != "clumps":
         assert total_looked < 0.1 * 4 * n_rays * len(sph)
     assert total_lit < 0.2 * 4 * n_rays
+
+
+def test_walk_with_each_spheres_own_inflation_at_the_rims_of_the_big_ones_from_far_origins():
+    """Registration inflates sphere i by the delta of ITS radius (pt_grid.hpp): a sphere of 20 x rmin gets a small fraction
+    of delta_g.  The case that margin is for: rays from as far away as a walking ray can start (|o - c0| up to 2 s0), aimed at
+    the rims of the biggest gridded spheres of a wide scene with very mixed radii — where the shader's own rounding decides
+    whether and where the ray hits.  The fp32 emulation of the kernel's walk must return hit_world's pair.
+    (A regression guard, not the proof: a margin that is too small shows only when a rounded hit point also falls across a
+    cell boundary, which random rays practically never do — this test passes with NO inflation at all.  The margin's size
+    is the per-sphere bound |P(v) - C| <= sqrt(r^2 + 32 u D^2) + 10 u r, which test_root_stays_within_delta_of_the_sphere
+    measures pair by pair with the sphere's own r.)"""
+    rng = np.random.default_rng(77)
+    n = 700
+    sph = random_field(n, 21, extent=90.0, rmax=0.1, giants=1)
+    big = rng.random(n) < 0.3
+    big[0] = False
+    sph["radius"][big] = rng.uniform(1.0, 2.5, int(big.sum())).astype(np.float32)
+    rc, g = build(sph)
+    assert rc == 0
+    gridded = np.unique(g["index"][:g["n_cell_entries"]])
+    r_all = np.abs(np.asarray(sph["radius"], np.float64))
+    big_gridded = gridded[r_all[gridded] >= 1.0]
+    assert len(big_gridded) > 50 and r_all[gridded].min() < 0.06                 # mixed radii IN the cells
+    x40 = 40.0 * U * float(g["d_near"]) ** 2
+    first_small = np.sqrt(float(g["rmin"]) ** 2 + x40) - float(g["rmin"])
+    first_big = np.sqrt(1.0 + x40) - 1.0
+    assert first_big < 0.4 * first_small and first_small > 0.02 * float(g["rmin"])  # the margins really differ, and matter
+    c = np.asarray(sph["center"], np.float64)
+    c0, s0 = g["c0"].astype(np.float64), float(g["s0"])
+    bad_total = hits = 0
+    for seed in range(3):
+        r2 = np.random.default_rng(100 + seed)
+        m = 3000
+        u = r2.normal(size=(m, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+        o = c0 + u * (s0 * r2.uniform(1.2, 1.98, (m, 1)))                           # far, but still walking rays
+        j = r2.choice(big_gridded, m)
+        v = r2.normal(size=(m, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+        # a rim point as seen from o: offset perpendicular to the line of sight
+        los = c[j] - o; los /= np.linalg.norm(los, axis=1)[:, None]
+        v -= np.einsum("ij,ij->i", v, los)[:, None] * los; v /= np.linalg.norm(v, axis=1)[:, None]
+        target = c[j] + v * r_all[j, None] * r2.choice([0.9999, 0.999999, 1.0, 1.000001, 1.0001], (m, 1))
+        d = (target - o) * r2.choice([1.0, 0.01, 3.0], (m, 1))
+        o32, d32 = f32(o), f32(d)
+        ref_t, ref_i = brute_force(o32, d32, sph)
+        got_t, got_i, looked, literal = walk(g, o32, d32, sph)
+        chk = ~literal
+        assert chk.mean() > 0.9                                                      # they do walk
+        bad = chk & ((got_i != ref_i) | (got_t.view(np.uint32) != ref_t.view(np.uint32)))
+        bad_total += int(bad.sum()); hits += int((ref_i[chk] >= 0).sum())
+        assert not bad.any(), (seed, np.nonzero(bad)[0][:5], got_i[bad][:5], ref_i[bad][:5])
+    assert hits > 2000
 
 
 def _morton(x, y, z):
