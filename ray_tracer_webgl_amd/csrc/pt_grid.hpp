@@ -29,7 +29,7 @@
 //
 //     delta_g = delta(d_near) + eps_dda
 //
-// touches (each sphere with the delta of its OWN radius in the first term: delta_i <= delta_g), and rays with |o - c0| + s0 <= d_near (= 3 s0: every ray that starts within 2 s0 of
+// touches (each sphere with the delta of its OWN radius and distance bound in the first term: delta_i <= delta_g), and rays with |o - c0| + s0 <= d_near (= 3 s0: every ray that starts within 2 s0 of
 // the scene's middle) walk the cells.  The rare ray from farther away first tests the grid's
 // bounding box inflated by its own delta(D); if it misses, no gridded sphere can be hit; if it
 // enters, the lane falls back to the literal loop over the whole list (measured on config 2 and
@@ -258,15 +258,24 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     if (n_cells > (1u << 22)) return false;
     // ---- registration --------------------------------------------------------------------------
     std::vector<uint32_t> count(n_cells, 0);
-    // (the inflation of sphere i: delta of ITS radius — sqrt(r^2 + x) - r decreases with r, a sphere of five times rmin
-    // needs less than half of delta_g's first term — plus what delta_g carries beyond that term for the walk's rounding;
-    // never more than delta_g, which stays the bound of every registered box.  Config 5, radii 0.1 ... 0.5 in a scene
-    // of extent 150: 24 127 -> 21 423 entries in the cells, 1.51 -> 1.40 leaf rounds per visited cell)
-    const double u40 = 40.0 * 5.9604644775390625e-08 * (double)g.d_near * (double)g.d_near;
-    const double dg_walk = (double)g.delta_g - (std::sqrt(rmin * rmin + u40) - rmin);
-    auto range = [&](uint32_t i, int k, uint32_t& a, uint32_t& b) {
+    // (the inflation of sphere i: delta with ITS radius and ITS distance bound in the first term — sqrt(r^2 + x) - r
+    // decreases with r, a sphere of five times rmin needs less than half of delta_g's first term; and a walking ray starts
+    // within d_near - s0 of c0 (the kernel's near test), hence within D_i = d_near - s0 + |C_i - c0| <= d_near of C_i —
+    // plus what delta_g carries beyond that term for the walk's rounding; never more than delta_g, which stays the bound
+    // of every registered box.  Config 5, radii 0.1 ... 0.5 in a scene of extent 150: 24 127 -> 21 423 (own radius) ->
+    // 20 504 (own distance) entries in the cells, 1.51 -> 1.40 -> 1.37 leaf rounds per visited cell)
+    const double u40 = 40.0 * 5.9604644775390625e-08;
+    const double dg_walk = (double)g.delta_g - (std::sqrt(rmin * rmin + u40 * (double)g.d_near * (double)g.d_near) - rmin);
+    std::vector<double> infl(n, 0.0);
+    for (uint32_t i = 0; i < n; i++) {
+      if (alw[i]) continue;
       const double ri = std::fabs((double)radius[i]);
-      const double r = ri + std::min((double)g.delta_g, (std::sqrt(ri * ri + u40) - ri) * (1.0 + 1e-9) + dg_walk);
+      const double dx = geom[4 * i] - (double)g.c0[0], dy = geom[4 * i + 1] - (double)g.c0[1], dz = geom[4 * i + 2] - (double)g.c0[2];
+      const double Di = std::min((double)g.d_near, ((double)g.d_near - (double)g.s0 + std::sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-6));
+      infl[i] = std::min((double)g.delta_g, (std::sqrt(ri * ri + u40 * Di * Di) - ri) * (1.0 + 1e-9) + dg_walk);
+    }
+    auto range = [&](uint32_t i, int k, uint32_t& a, uint32_t& b) {
+      const double r = std::fabs((double)radius[i]) + infl[i];
       double fa = std::floor(((double)geom[4 * i + k] - r - (double)g.lo[k]) / (double)g.h[k]);
       double fb = std::floor(((double)geom[4 * i + k] + r - (double)g.lo[k]) / (double)g.h[k]);
       fa = std::min(std::max(fa, 0.0), (double)g.n[k] - 1.0);

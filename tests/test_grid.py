@@ -128,13 +128,16 @@ def test_structure(name):
     # ... and is not absurd next to a cell
     assert g["delta_g"] < 0.6 * float(g["h"].min()) or name in ("clumps",) or name.endswith("_far")
     # registration: a sphere is an entry of EVERY cell its box inflated by ITS delta touches: the kernel's bound with the
-    # sphere's own radius in the square root (sqrt(r^2 + x) - r decreases with r) + what delta_g carries beyond that term
-    # (16 u rmax and the walk's rounding, eps_dda); at r = rmin that is delta_g itself
-    x40 = 40.0 * U * float(g["d_near"]) ** 2
-    dg_walk = float(g["delta_g"]) - (np.sqrt(float(g["rmin"]) ** 2 + x40) - float(g["rmin"]))
+    # sphere's own radius in the square root (sqrt(r^2 + x) - r decreases with r) and its own distance bound D_i = d_near - s0
+    # + |C_i - c0| (a walking ray starts within d_near - s0 of c0: the kernel's near test, r2_near) + what delta_g carries
+    # beyond that term (16 u rmax and the walk's rounding, eps_dda); at r = rmin, |C - c0| = s0 - r that is delta_g itself
+    d_near = float(g["d_near"])
+    assert float(g["r2_near"]) <= (d_near - s0) ** 2
+    dg_walk = float(g["delta_g"]) - (np.sqrt(float(g["rmin"]) ** 2 + 40.0 * U * d_near ** 2) - float(g["rmin"]))
     assert dg_walk >= 16.0 * U * float(g["rmax"])
-    delta_i = np.minimum(float(g["delta_g"]), np.sqrt(r * r + x40) - r + dg_walk)
-    assert np.all(delta_i[gridded] >= np.sqrt(r[gridded] ** 2 + x40) - r[gridded] + 16.0 * U * float(g["rmax"]) - 1e-12)
+    D_i = np.minimum(d_near, d_near - s0 + np.linalg.norm(c - c0, axis=1))
+    delta_i = np.minimum(float(g["delta_g"]), np.sqrt(r * r + 40.0 * U * D_i ** 2) - r + dg_walk)
+    assert np.all(delta_i[gridded] >= np.sqrt(r[gridded] ** 2 + 40.0 * U * D_i[gridded] ** 2) - r[gridded] + 16.0 * U * float(g["rmax"]) - 1e-12)
     lo, h, nn = g["lo"].astype(np.float64), g["h"].astype(np.float64), g["n"]
     member = {}
     for cell in np.nonzero(count)[0]:
