@@ -37,7 +37,16 @@
 // boundary-crossing times are sums of up to n per-axis increments, each rounded, so the cell
 // the walk stands in at its time t is within (n + 8) u |d| t of the cell that contains the exact
 // P(t); the slab test of the entry point and the evaluation of the cell boundaries are of the
-// same size.  The walk ends when it leaves the grid or when the closest accepted root lies
+// same size.  To first order, per axis k, in POSITION along the axis (time error x |d_k|), with
+// B = |c0|_inf + diag >= |plane|, L = d_near + diag >= |plane - o_k| and the ray's extent in the grid:
+//   first plane time fma(b, i, -fl(o i)), b = fma(cell + 1, h, lo) (u B), i = v_rcp_f32 (1 ulp = 2 u), the product
+//   (u |o_k|) and the fma's own rounding (u L):                                          <= u (3 L + B + |o_k|)
+//   m <= n_k running sums t += td, each rounded (u t), td = fl(h |i|) good to 3 u:         <= u (m L + 3 diag)
+// together <= u (n_k + 8) (d_near + diag + |c0|_inf); the builder takes n_sum = n_x + n_y + n_z for n_k and
+// EIGHT times the result (rounds 2-4: 32 times; measured by tests/test_grid.py
+// test_the_walks_boundary_times_stay_within_the_rounding_budget_of_the_registration: the fp32 walk against float64
+// planes, reciprocals perturbed by an ulp, scenes at the origin and 3 000 units away — the worst crossing lies
+// 0.03 ... 0.065 of the bound WITHOUT the factor off its plane).  The walk ends when it leaves the grid or when the closest accepted root lies
 // strictly before the current cell's exit time: a sphere not tested yet is registered only in
 // cells the walk reaches later, so its root is not smaller.
 //
@@ -245,7 +254,7 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
       // the walk's plane times are evaluated in absolute coordinates, so their position error scales
       // with |c0| + d_near (a scene centred far from the origin), not with d_near alone
       const double c0abs = std::max(std::fabs((double)g.c0[0]), std::max(std::fabs((double)g.c0[1]), std::fabs((double)g.c0[2])));
-      const double eps_dda = 32.0 * (n_sum + 8.0) * u * ((double)g.d_near + diag + c0abs);
+      const double eps_dda = 8.0 * (n_sum + 8.0) * u * ((double)g.d_near + diag + c0abs);
       // the kernel's per-ray delta carries 25 % slack on E' and is compared against this value
       const double need = (std::sqrt(rmin * rmin + 32.0 * 1.25 * u * (double)g.d_near * g.d_near) - rmin + 16.0 * u * rmax) + eps_dda;
       if (need <= dg) break;
