@@ -162,6 +162,75 @@ __device__ __forceinline__ uint32_t unorm8(float v) {
 // has received nothing reads as 0.
 __device__ __forceinline__ float pixel_scale(float w) { return w > 0.0f ? 1.0f / w : 0.0f; }
 
+// One texel of the shader's render() (static/shader.frag:387-404): the frame's colour sqrt(sum * scale), blended into the
+// previous frame's RGBA8 texel `pv` with the running-mean rule when averaging — as the statements read
+//     px = sqrt(v.xyz * scale);  pa = float(pv.a) / 255;  pr = float(pv.c) / 255;
+//     merged = (px * last_frame_weight + pr * rc) / (rc + last_frame_weight);  o.c = unorm8(merged)
+// with the same correctly rounded results from cheaper sequences (pt_arith.hpp: sqrt_core and div_core ARE the compiler's
+// expansions of sqrtf and `/` without their range scaling, valid where the scaling is the identity):
+//   * sqrt_core for an operand that is 0 or in [2^-96, +inf] (it returns 0 for 0, inf for inf);
+//   * byte / 255 through div_core with ONE Newton reciprocal of 255 per thread: 255 is a normal denominator, the numerator
+//     0 or >= 1 (div_core returns +0 for +0);
+//   * merged / total through div_core with one reciprocal per frame when total is in [2^-20, 2^20) and the numerator is 0
+//     or in [2^-103, 2^76);
+//   * `pa == 0.0` is `pv.a == 0` (a byte over 255 is zero for the zero byte only): no division at all.
+// A lane whose operands lie outside those ranges (a colour below 2^-96, a NaN, a weight of 1e-30 ...) takes the plain
+// operators, wave by wave and practically never.  Per texel 12 + 3 x 14 + 12 + 3 x 12 + 3 x 12 vector instructions of
+// division and square root become 12 + 3 x 9 + 0 + 3 x 5 + 3 x 5 (+ 3 per frame, + 3 per thread).
+struct BlendRule {
+  float rc, lfw, total, y_total, y255;
+  bool averaging;  // should_average && render_count > 1 (wave-uniform)
+  bool total_ok;   // total is a denominator for div_core (wave-uniform)
+};
+__device__ __forceinline__ BlendRule blend_rule(int render_count, int should_average, float last_frame_weight) {
+  BlendRule B;
+  B.rc = (float)render_count;
+  B.lfw = last_frame_weight;
+  B.total = B.rc + last_frame_weight;
+  B.total_ok = ptk::div_den_ok(B.total);
+  B.y_total = ptk::rcp_newton(B.total_ok ? B.total : 1.0f);
+  B.y255 = ptk::rcp_newton(255.0f);
+  B.averaging = should_average && render_count > 1;
+  return B;
+}
+__device__ __forceinline__ uint32_t blend_texel(const float4 v, const uint32_t pv, const BlendRule& B) {
+  using namespace ptk;
+  const float scale = pixel_scale(v.w);
+  const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale;
+  float px[3] = {sqrt_core(x0), sqrt_core(x1), sqrt_core(x2)};
+  // operands sqrt_core does not cover: 0 < x < 2^-96, negative, NaN  (bit patterns: not 0 and not in [2^-96, +inf])
+  const uint32_t lo = f2u(0x1p-96f), span = 0x7f800000u - f2u(0x1p-96f);
+  bool odd = (f2u(x0) != 0u && f2u(x0) - lo > span) || (f2u(x1) != 0u && f2u(x1) - lo > span) || (f2u(x2) != 0u && f2u(x2) - lo > span);
+  uint32_t o = 255u << 24;
+  const bool merge = B.averaging && (pv >> 24) != 0u;
+  float m[3] = {px[0], px[1], px[2]};
+  if (B.averaging) {  // wave-uniform
+    const float n_lo = 0x1p-103f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float pr = div_core((float)((pv >> (8 * c)) & 255u), 255.0f, B.y255);
+      const float num = fma_(px[c], B.lfw, pr * B.rc);
+      const float q = div_core(num, B.total, B.y_total);
+      odd = odd || (merge && !(B.total_ok && (f2u(num) == 0u || f2u(num) - f2u(n_lo) < f2u(0x1p76f) - f2u(n_lo))));
+      m[c] = merge ? q : px[c];
+    }
+  }
+  if (__builtin_expect(pt_ballot(odd) != 0ull, 0)) {  // (rare) the statements as they read
+    if (odd) {
+      m[0] = px[0] = __builtin_sqrtf(x0); m[1] = px[1] = __builtin_sqrtf(x1); m[2] = px[2] = __builtin_sqrtf(x2);
+      if (merge) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
+          m[c] = fma_(px[c], B.lfw, pr * B.rc) / B.total;
+        }
+      }
+    }
+  }
+  o |= unorm8(m[0]) | (unorm8(m[1]) << 8) | (unorm8(m[2]) << 16);
+  return o;
+}
+
 extern "C" __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* accum, float4* out,
                                                                     uint32_t n_pix, int gamma) {
   uint32_t stride = gridDim.x * blockDim.x;
@@ -192,27 +261,9 @@ extern "C" __global__ __launch_bounds__(256) void pt_blend_rgba8_kernel(
     const float4* accum, const uint32_t* prev, uint32_t* out, uint32_t n_pix,
     int render_count, int should_average, float last_frame_weight) {
   uint32_t stride = gridDim.x * blockDim.x;
-  float rc = (float)render_count;
+  const BlendRule B = blend_rule(render_count, should_average, last_frame_weight);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
-    float4 v = accum[i];
-    const float scale = pixel_scale(v.w);
-    float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale),
-                   __builtin_sqrtf(v.z * scale)};
-    uint32_t pv = prev[i];
-    float pa = (float)(pv >> 24) / 255.0f;
-    uint32_t o = 255u << 24;
-    if (should_average && !(pa == 0.0f || render_count <= 1)) {
-      float total = rc + last_frame_weight;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
-        float merged = fma_(px[c], last_frame_weight, pr * rc) / total;
-        o |= unorm8(merged) << (8 * c);
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
-    }
+    const uint32_t o = blend_texel(accum[i], prev[i], B);
     out[i] = o;
   }
 }
@@ -239,27 +290,9 @@ extern "C" __global__ __launch_bounds__(256) void pt_frame_blend_kernel(
   const uint32_t* prev = ((even_odd + 1u) & 1u) ? tex1 : tex0;
   uint32_t* out_tex = (even_odd & 1u) ? tex1 : tex0;
   uint32_t stride = gridDim.x * blockDim.x;
-  float rc = (float)render_count;
+  const BlendRule B = blend_rule(render_count, should_average, last_frame_weight);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
-    float4 v = slab[i];
-    const float scale = pixel_scale(v.w);
-    float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale),
-                   __builtin_sqrtf(v.z * scale)};
-    uint32_t pv = prev[i];
-    float pa = (float)(pv >> 24) / 255.0f;
-    uint32_t o = 255u << 24;
-    if (should_average && !(pa == 0.0f || render_count <= 1)) {
-      float total = rc + last_frame_weight;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
-        float merged = fma_(px[c], last_frame_weight, pr * rc) / total;
-        o |= unorm8(merged) << (8 * c);
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
-    }
+    const uint32_t o = blend_texel(slab[i], prev[i], B);
     canvas[i] = o;
     if (should_average) out_tex[i] = o;
   }
@@ -280,36 +313,34 @@ extern "C" __global__ __launch_bounds__(256) void pt_frames_blend_kernel(
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
     uint32_t pv = 0u, o = 0u;
-    for (uint32_t f = 0; f < n_frames; f++) {
+    // one frame of the chain (its slab value already in a register)
+    auto frame = [&](uint32_t f, const float4 v) {
       const uint32_t k = k0 + f;
       const long long rc_ll = (long long)render_count0 + (long long)k;
       const int render_count = rc_ll < (long long)max_render_count ? (int)rc_ll : max_render_count;
-      const float rc = (float)render_count;
+      const BlendRule B = blend_rule(render_count, should_average, last_frame_weight);
       const uint32_t even_odd = even_odd0 + k;
       // the previous frame's texel: from memory for the group's first frame (and always when nothing is written
       // back), from the register afterwards
       if (f == 0u || !should_average) pv = (((even_odd + 1u) & 1u) ? tex1 : tex0)[i];
       else pv = o;
-      const float4 v = slab[(size_t)f * n_pix + i];
-      const float scale = pixel_scale(v.w);
-      float px[3] = {__builtin_sqrtf(v.x * scale), __builtin_sqrtf(v.y * scale), __builtin_sqrtf(v.z * scale)};
-      const float pa = (float)(pv >> 24) / 255.0f;
-      o = 255u << 24;
-      if (should_average && !(pa == 0.0f || render_count <= 1)) {
-        const float total = rc + last_frame_weight;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float pr = (float)((pv >> (8 * c)) & 255u) / 255.0f;
-          const float merged = fma_(px[c], last_frame_weight, pr * rc) / total;
-          o |= unorm8(merged) << (8 * c);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; c++) o |= unorm8(px[c]) << (8 * c);
-      }
+      o = blend_texel(v, pv, B);
       // what reaches memory: the last two frames' textures (earlier ones are overwritten by them), the last canvas
       if (should_average && f + 2u >= n_frames) ((even_odd & 1u) ? tex1 : tex0)[i] = o;
+    };
+    // A pixel's blends are a chain, its slab loads are not: EIGHT frames' values are requested before the first of them is
+    // blended (the chain alone — one load, then ~100 instructions, 64 times over — left the kernel waiting on memory at
+    // 3.3 TB/s with every wave slot of the chip taken; 0.245 -> 0.220 ms per group of 64 frames; one pixel per thread — 3 510
+    // workgroups instead of 2 048 — 0.232: profiles/r05_ab_runs.txt)
+    uint32_t f = 0;
+    for (; f + 8u <= n_frames; f += 8u) {
+      float4 v[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8u; j++) v[j] = slab[(size_t)(f + j) * n_pix + i];
+#pragma unroll
+      for (uint32_t j = 0; j < 8u; j++) frame(f + j, v[j]);
     }
+    for (; f < n_frames; f++) frame(f, slab[(size_t)f * n_pix + i]);
     canvas[i] = o;
   }
 }

@@ -464,6 +464,40 @@ def test_temporal_blend_rgba8(ora):
     t.close()
 
 
+def test_temporal_blend_rgba8_at_the_edges_of_its_fast_forms(ora):
+    """The blend kernels take sqrt and the three kinds of division through the unscaled forms of pt_arith.hpp where those
+    are the compiler's own sequences, and through the plain operators elsewhere (pt_kernels.hip blend_texel).  Operands on
+    both sides of every guard: colours of 0, below 2^-96 (subnormal too), huge, infinite, NaN and negative; every byte
+    value in every channel against alpha 0 / 1 / 255; weights of 1e-30 (numerators below 2^-103), 1e30, 0; render counts
+    whose total leaves [2^-20, 2^20).  Bit for bit the oracle's statement-by-statement blend."""
+    sc = scenes.default_scene(64, 36, spp=4, max_depth=8)
+    t, acc0 = render_scene(sc)
+    rng = np.random.default_rng(44)
+    acc = np.array(acc0, np.float32)
+    h, w = acc.shape[:2]
+    special = np.array([0.0, 1e-45, 1e-40, 2.0 ** -100, 2.0 ** -96 * 4 * 0.999, 2.0 ** -96 * 4, 2.0 ** -94, 1e-20, 1e-10, 0.5, 4.0, 7.99, 1e10,
+                        3e38, np.inf, np.nan, -0.0, -1e-30, -1.0], np.float32)
+    pick = rng.random((h, w, 3)) < 0.5
+    acc[..., :3] = np.where(pick, rng.choice(special, (h, w, 3)), acc[..., :3])
+    acc[..., 3] = 4.0
+    prev = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    prev[:, :16, 0] = np.arange(h * 16).reshape(h, 16) % 256   # every byte value, in every channel
+    prev[:, 16:32, 1] = (np.arange(h * 16).reshape(h, 16) + 97) % 256
+    prev[:, 32:48, 2] = (np.arange(h * 16).reshape(h, 16) + 191) % 256
+    prev[..., 3] = rng.choice(np.array([0, 1, 128, 255], np.uint8), (h, w))
+    t.load_accum(acc)
+    for rc, avg, wt in [(0, 1, 1.0), (1, 1, 1.0), (2, 1, 1.0), (37, 1, 0.5), (5, 0, 1.0), (3, 1, 1e-30), (3, 1, 1e-38), (2, 1, 1e30), (2, 1, 0.0),
+                        (1 << 20, 1, 1.0), ((1 << 20) - 1, 1, 0.5), (2_000_000_000, 1, 1.0), (2, 1, 3e38), (7, 1, float("inf")), (7, 1, float("nan")),
+                        (9, 1, -9.0), (9, 1, -1.0)]:
+        p = sc.params.copy()
+        p.render_count, p.should_average, p.last_frame_weight = rc, avg, wt
+        t.set_params(p)
+        got = t.blend_rgba8(prev)
+        ref = ora.blend_rgba8(acc, 4, p, prev)
+        assert np.array_equal(got, ref), (rc, avg, wt, int((got != ref).sum()), np.argwhere(got != ref)[:4])
+    t.close()
+
+
 def test_torch_owned_accumulation_and_stream(ora):
     import torch
 
