@@ -225,7 +225,11 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     }
     g.s0 = round_up(s0 * (1.0 + 1e-6));
     g.rmin = round_down(rmin); g.rmax = round_up(rmax);
-    g.d_near = round_up(3.0 * (double)g.s0);
+    double near_factor = 3.0;  // rays that start within (near_factor - 1) s0 of the scene's middle walk the cells
+#ifdef PT_DEV_KNOBS
+    if (const char* e = std::getenv("PT_GRID_DNEAR")) { const double v = std::atof(e); if (v >= 2.0 && v <= 6.0) near_factor = v; }
+#endif
+    g.d_near = round_up(near_factor * (double)g.s0);
     // ---- resolution --------------------------------------------------------------------------
     double diag = 0.0;
     uint32_t n_sum = 0;
