@@ -245,22 +245,34 @@ __device__ __forceinline__ void grid_walk(const PtKernelArgs& A, const Path& p, 
     if (m_has == 0ull) break; // no cell under test and nobody can move: every walk is over
     tally.leaf(m_has);
     {
-      // four consecutive entries of the cell under test (those beyond its count belong to the
-      // next cell or to the slack behind the array: tested, then masked)
+      // G = 4 consecutive entries of the cell under test (those beyond its count belong to the next cell or to the
+      // slack behind the array: tested, then masked).  Where every lane GATHERS its entries from global memory (scenes of
+      // thousands of spheres) a round costs its gather instructions — ~30 cycles of the CU's vector-memory pipe each, the
+      // pipe 92 % busy on config 5 — and a cell of 3.7 entries on average would be read with fewer of them three or two
+      // at a time (1.58 rounds x 3 = 4.75 or 2.12 x 2 = 4.24 gathers per visited cell instead of 1.33 x 4 = 5.31).
+      // Measured (PT_LEAF_GROUP_GMEM = 3 / 2, profiles/r05_ab_runs.txt): config 5 +0.6 % / +9 %: what the rounds save in
+      // gathers they cost in trips of this loop, each a dependent round trip to the L1.  Four it stays.
+      constexpr uint32_t G = S::WALK == 4 ? 4u : (uint32_t)PT_LEAF_GROUP_GMEM;
+      static_assert(G >= 2u && G <= 4u, "a leaf round tests two, three or four entries");
       const uint32_t base = pend & 0xffffffu;
       const uint32_t left = pend >> 24;
       tally.leaf_cells(A, has, base, A.n_slots);
-      const float4 g0 = S::slot_at(A, base), g1 = S::slot_at(A, base + 1u), g2 = S::slot_at(A, base + 2u), g3 = S::slot_at(A, base + 3u);
-      float hb0, cc0, ds0; sphere_test(o, d, a, g0, hb0, cc0, ds0);
-      float hb1, cc1, ds1; sphere_test(o, d, a, g1, hb1, cc1, ds1);
-      float hb2, cc2, ds2; sphere_test(o, d, a, g2, hb2, cc2, ds2);
-      float hb3, cc3, ds3; sphere_test(o, d, a, g3, hb3, cc3, ds3);
+      float4 g[4];
+#pragma unroll
+      for (uint32_t k = 0; k < G; k++) g[k] = S::slot_at(A, base + k);
+      float hb[4], cc[4], ds[4];
+#pragma unroll
+      for (uint32_t k = 0; k < G; k++) sphere_test(o, d, a, g[k], hb[k], cc[k], ds[k]);
+#pragma unroll
+      for (uint32_t k = G; k < 4u; k++) { hb[k] = hb[G - 1u]; ds[k] = ds[G - 1u]; }  // (never selected: the mask has G bits)
       // (no `if (has)` around this: a lane without a cell under test has left == 0, so its mask is empty and
       // its pend becomes 0 — which is all that `pend < 2^24` meant for it)
-      uint32_t mask = pass_bit(hb0, cc0, ds0) | (pass_bit(hb1, cc1, ds1) << 1) | (pass_bit(hb2, cc2, ds2) << 2) | (pass_bit(hb3, cc3, ds3) << 3);
-      mask &= left >= 4u ? 0xfu : ((1u << left) - 1u);
-      pend = left > 4u ? (base + 4u) | ((left - 4u) << 24) : 0u;
-      exact_group(base, mask, hb0, hb1, hb2, hb3, ds0, ds1, ds2, ds3);
+      uint32_t mask = 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < G; k++) mask |= pass_bit(hb[k], cc[k], ds[k]) << k;
+      mask &= left >= G ? ((1u << G) - 1u) : ((1u << left) - 1u);
+      pend = left > G ? (base + G) | ((left - G) << 24) : 0u;
+      exact_group(base, mask, hb[0], hb[1], hb[2], hb[3], ds[0], ds[1], ds[2], ds[3]);
       // the cell is done: can anything registered only in later cells still win?
       rem = (has && pend < 0x1000000u && closest < t_exit) ? 0u : rem;
     }

@@ -118,6 +118,9 @@ struct PtKernelArgs {
 #endif
 #define PT_WAVES_TWIN_CELLS 4 // the measuring twin of the cells-only grid kernel (98 VGPRs with its tallies live)
 #define PT_BUILT_FOR(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#ifndef PT_LEAF_GROUP_GMEM
+#define PT_LEAF_GROUP_GMEM 4  // entries a leaf round of the grid walk tests where they are gathered from global memory (pt_grid_walk.hpp)
+#endif
 
 enum { PT_WAVE_LOG_WORDS = 4 };
 enum { PT_COH_BINS = 66, PT_HIST_WAVE_STRIDE = 8 };  // cell_hist: bins 0..64 = distinct entry runs in a sampled leaf round, bin 65 = sampled rounds' lanes  // u64 per wave in PtKernelArgs.wave_log
