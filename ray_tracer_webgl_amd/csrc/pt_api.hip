@@ -479,7 +479,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     if (c->d_mat) PT_HIP(c, hipFree(c->d_mat));
     c->d_geom = nullptr; c->d_mat = nullptr;
     PT_HIP(c, hipMalloc(&c->d_geom, (size_t)PT_LDS_ENTRIES(n) * 16));
-    PT_HIP(c, hipMalloc(&c->d_mat, (size_t)(n ? n : 1) * sizeof(PtMatRec)));
+    PT_HIP(c, hipMalloc(&c->d_mat, (size_t)(n ? n : 1) * (sizeof(PtMatRec) + 2 * sizeof(float))));  // (+ the r0 pairs behind the records)
     c->sphere_cap = n;
   }
   // split into the 16-byte geometry record the intersection loop stages into LDS and the 32-byte
@@ -539,6 +539,20 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   }
   if (n) {
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), (size_t)n * sizeof(PtMatRec), hipMemcpyHostToDevice));
+    // reflectance()'s r0 = ((1 - ratio) / (1 + ratio))^2 (static/shader.frag:205) for both ratios a GLASS sphere is entered
+    // with, 1 / ri (front face) and ri: a subtraction, an addition, an IEEE division and a product in fp32 under
+    // -ffp-contract=off give the same bits here as in the kernel.  Read by the small-list kernels only (pt_shade.hpp): in
+    // the closed room (config 4) the GLASS branch runs in 95 % of the wave steps for 3.6 lanes, and a division is a dozen
+    // instructions for the whole wave (config 4 -1 %, State::default -1 %; the kernels of the large scenes sit at their
+    // register limits and measured +1 % with it: they keep the division)
+    std::vector<float> r0(2 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+      const float front = mat[i].inv_ri, back = mat[i].refraction_index;
+      const float qf = (1.0f - front) / (1.0f + front), qb = (1.0f - back) / (1.0f + back);
+      r0[2 * i] = qf * qf;
+      r0[2 * i + 1] = qb * qb;
+    }
+    PT_HIP(c, hipMemcpy(reinterpret_cast<char*>(c->d_mat) + (size_t)c->sphere_cap * sizeof(PtMatRec), r0.data(), r0.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   c->have_bvh = false;
   if (have_bvh) {
@@ -865,6 +879,7 @@ static int fill_uniforms(pt_ctx* c, uint32_t n_passes, PtKernelArgs& A) {
   A.div_band_rows = pt_div_make(A.band_rows);
   A.geom = c->d_geom;
   A.mat = c->d_mat;
+  A.mat_r0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(c->d_mat) + (size_t)c->sphere_cap * sizeof(PtMatRec));
   A.slab = reinterpret_cast<float*>(c->d_slab);
   A.counters = c->d_counters;
   A.tile_order = c->d_tile_order;

@@ -95,6 +95,8 @@ struct PtKernelArgs {
                                    // (sampled: every 8th wave), then PT_COH_BINS bins of "distinct runs among a leaf round's lanes"
   const uint32_t* frame_ctr;       // device cell added to the pass number in u_time (pt_render_frames: frames replayed from a
                                    // hipGraph advance it on the device); points at a zero cell otherwise.  Never NULL.
+  const float* mat_r0;             // n_spheres x {r0 of reflectance() for the ratio 1 / ri, for the ratio ri}: ((1 - ratio) / (1 + ratio))^2 made on the host (small-list kernels)
+                                   // (last: the other kernels' argument offsets — and with them their scalar loads and spills — stay as they were)
 };
 
 // ---- waves per SIMD each trace kernel is BUILT FOR -------------------------------------------------------------

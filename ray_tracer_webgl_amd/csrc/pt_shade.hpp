@@ -119,7 +119,14 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
       float cos_theta = (1.0f < cdot) ? 1.0f : cdot; // min(cdot, 1.0)
       float sin_theta = sqrt_rn(fma_(-cos_theta, cos_theta, 1.0f));
       bool cannot_refract = ratio * sin_theta > 1.0f;
-      float refl_amount = reflectance(cos_theta, ratio);
+      float refl_amount;
+      if constexpr (S::SMALL) {  // r0 from the host: the same bits as reflectance()'s own (pt_api.hip pt_set_spheres)
+        const float r0 = A.mat_r0[2u * (uint32_t)hit + (front ? 0u : 1u)];
+        const float x = 1.0f - cos_theta, x2 = x * x, x5 = (x2 * x2) * x;
+        refl_amount = fma_(1.0f - r0, x5, r0);
+      } else {
+        refl_amount = reflectance(cos_theta, ratio);
+      }
       float rnd = (float)draw * (1.0f / 4294967296.0f); // hash1 :21-24
       V3 nd;
       if (cannot_refract || refl_amount > rnd) {
