@@ -1430,6 +1430,9 @@ def test_every_launched_wave_is_resident(which):
     t.reserve_passes(n)
     t.set_geometry_path(path)
     t.set_count_work(True)
+    t.render_passes(n)  # (cold: the twin's code object, the machine's clocks — the log read below is the second launch's)
+    t.synchronize()
+    t.reset()
     t.render_passes(n)
     buf = np.zeros((20000, 4), np.uint64)
     t.lib.pt_debug_wave_log.restype = C.c_long
