@@ -543,8 +543,8 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     // with, 1 / ri (front face) and ri: a subtraction, an addition, an IEEE division and a product in fp32 under
     // -ffp-contract=off give the same bits here as in the kernel.  Read by the small-list kernels only (pt_shade.hpp): in
     // the closed room (config 4) the GLASS branch runs in 95 % of the wave steps for 3.6 lanes, and a division is a dozen
-    // instructions for the whole wave (config 4 -1 %, State::default -1 %; the kernels of the large scenes sit at their
-    // register limits and measured +1 % with it: they keep the division)
+    // instructions for the whole wave (config 4 -0.7 %, State::default within the boxes' spread; the kernels of the large scenes
+    // sit at their register limits and measured +1 % with it: they keep the division; profiles/r05_ab_runs.txt)
     std::vector<float> r0(2 * (size_t)n);
     for (uint32_t i = 0; i < n; i++) {
       const float front = mat[i].inv_ri, back = mat[i].refraction_index;

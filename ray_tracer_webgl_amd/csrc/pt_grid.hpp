@@ -57,8 +57,8 @@
 // Layout produced:
 //   cells   : n[0]*n[1]*n[2] records, x fastest: first entry | n_entries << 24 (a leaf round of the
 //             kernel tests four consecutive entries and masks those beyond the cell's count)
-//   entries : {cx, cy, cz, r*r} copies, cell after cell without padding (config 2: 1 081 entries
-//             for 480 gridded spheres — 17 KB of LDS, which is what lets six waves per SIMD
+//   entries : {cx, cy, cz, r*r} copies, cell after cell without padding (config 2: 794 entries
+//             for 480 gridded spheres — 13 KB of LDS, which is what lets six waves per SIMD
 //             fit), then the always-tested spheres, padded to four with entries that can never
 //             pass (r*r = -inf)
 //   entry_index : original sphere index per entry (0xffffffff = padding)
