@@ -318,7 +318,11 @@ int pt_write_texture(pt_ctx* ctx, int index, const uint8_t* rgba_in);
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 int pt_get_stats(pt_ctx* ctx, PtStats* out);
 int pt_set_option(pt_ctx* ctx, int key, int value);
-/* Settles PT_GEOM_AUTO now instead of lazily: renders n_passes passes with the current scene
+/* Fits the context to scene AND uniforms.  (i) The uniform grid pt_set_spheres built for rays that start within twice
+ * the scene's radius of its middle is rebuilt for the smallest margin class that covers the camera set by pt_set_params
+ * (closer cameras: fewer copies per sphere; a camera far out: a grid that serves its rays at all) — speed only, the image
+ * does not depend on it; skipped once a launch has been captured into a caller's hipGraph.  (ii) Settles PT_GEOM_AUTO now
+ * instead of lazily: renders n_passes passes with the current scene
  * and uniforms once cold and once per usable path, keeps the fastest path, then clears the
  * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes.
  * Call it before capturing pt_render* into a hipGraph: a captured launch keeps the path it was

@@ -85,6 +85,9 @@ struct pt_ctx {
   float bvh_c0[3] = {0, 0, 0}, bvh_s0 = 0, bvh_kinv = 1;
   // uniform grid (PT_GEOM_GRID), rebuilt by pt_set_spheres; absent for tiny / irregular scenes
   bool have_grid = false;
+  // host copies of what the grid is built from: pt_tune rebuilds it for the view (fit_grid_to_view)
+  std::vector<float> h_geom, h_radii;
+  std::vector<PtMatRec> h_mat;
   uint32_t* d_grid_cells = nullptr;
   float* d_grid_entries = nullptr;
   uint32_t* d_grid_index = nullptr;
@@ -467,6 +470,65 @@ PT_API int pt_set_stream(pt_ctx* c, void* hip_stream) {
   return PT_OK;
 }
 
+namespace {
+
+// the uniform grid of PT_GEOM_GRID for a scene, laid out for the kernel that will read it
+bool build_grid(const float* geom, const float* radii, uint32_t n, double near_factor, ptgrid::Grid* grid) {
+  if (!ptgrid::build(geom, radii, n, grid, near_factor)) return false;
+  // entries that will not be staged in the LDS (bind_grid) are gathered from L2: their runs in Morton order of the cells
+  if (PT_GRID_LDS_CELLS(grid->cells.size()) + (size_t)grid->n_entries * 16 > walk_lds_room()) {
+    int mode = 2;
+#ifdef PT_DEV_KNOBS  // A/B only: PT_PAD_RUNS = 0 plain layout, 1 padded runs in Morton order, 2 Morton order (default), 3 padded runs
+    if (getenv("PT_PAD_RUNS")) mode = atoi(getenv("PT_PAD_RUNS"));
+#endif
+    if (mode) (void)ptgrid::morton_runs(grid, mode != 2, mode != 3);
+  }
+  return true;
+}
+
+// upload a grid (the caller has made sure that nothing in flight reads the previous one); empties the host arrays of `grid`
+int install_grid(pt_ctx* c, ptgrid::Grid& grid, const PtMatRec* mat, uint32_t n) {
+  const size_t n_cells_pad = (grid.cells.size() + 3u) & ~(size_t)3u;  // the kernels stage 16 B at a time
+  if (n_cells_pad > c->grid_cell_cap) {
+    if (c->d_grid_cells) PT_HIP(c, hipFree(c->d_grid_cells));
+    c->d_grid_cells = nullptr; c->grid_cell_cap = 0;
+    PT_HIP(c, hipMalloc(&c->d_grid_cells, n_cells_pad * sizeof(uint32_t)));
+    c->grid_cell_cap = n_cells_pad;
+  }
+  // + four entries of slack: a leaf round reads four consecutive entries whatever the cell's
+  // count (and lanes without a cell under test read, and discard, wherever their stale record points)
+  const size_t n_ent_pad = (size_t)grid.n_entries + 4u;
+  if (n_ent_pad > c->grid_entry_cap) {
+    if (c->d_grid_entries) PT_HIP(c, hipFree(c->d_grid_entries));
+    if (c->d_grid_index) PT_HIP(c, hipFree(c->d_grid_index));
+    if (c->d_grid_mat) PT_HIP(c, hipFree(c->d_grid_mat));
+    c->d_grid_entries = nullptr; c->d_grid_index = nullptr; c->d_grid_mat = nullptr; c->grid_entry_cap = 0;
+    PT_HIP(c, hipMalloc(&c->d_grid_entries, n_ent_pad * 16));
+    PT_HIP(c, hipMalloc(&c->d_grid_index, n_ent_pad * sizeof(uint32_t)));
+    PT_HIP(c, hipMalloc(&c->d_grid_mat, n_ent_pad * sizeof(PtMatRec)));
+    c->grid_entry_cap = n_ent_pad;
+  }
+  PT_HIP(c, hipMemset(c->d_grid_cells, 0, n_cells_pad * sizeof(uint32_t)));
+  PT_HIP(c, hipMemcpy(c->d_grid_cells, grid.cells.data(), grid.cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  PT_HIP(c, hipMemset(c->d_grid_entries, 0, n_ent_pad * 16));
+  PT_HIP(c, hipMemcpy(c->d_grid_entries, grid.entries.data(), (size_t)grid.n_entries * 16, hipMemcpyHostToDevice));
+  PT_HIP(c, hipMemset(c->d_grid_index, 0xff, n_ent_pad * sizeof(uint32_t)));
+  PT_HIP(c, hipMemcpy(c->d_grid_index, grid.entry_index.data(), (size_t)grid.n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    std::vector<PtMatRec> sm(n_ent_pad);
+    for (size_t k = 0; k < (size_t)grid.n_entries; k++) sm[k] = grid.entry_index[k] < n ? mat[grid.entry_index[k]] : PtMatRec{};
+    PT_HIP(c, hipMemcpy(c->d_grid_mat, sm.data(), sm.size() * sizeof(PtMatRec), hipMemcpyHostToDevice));
+  }
+  grid.cells.clear(); grid.cells.shrink_to_fit();
+  grid.entries.clear(); grid.entries.shrink_to_fit();
+  grid.entry_index.clear(); grid.entry_index.shrink_to_fit();
+  c->grid = grid;
+  c->have_grid = true;
+  return PT_OK;
+}
+
+} // namespace
+
 PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   if (!c || (!s && n)) return fail(c, PT_ERR_INVALID, "pt_set_spheres: NULL argument");
   if (n > PT_MAX_SPHERES)
@@ -519,15 +581,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
   const double t_bvh = host_ms();
   // ... and the uniform grid of PT_GEOM_GRID (same precondition)
   ptgrid::Grid grid;
-  const bool have_grid = regular && ptgrid::build(geom.data(), radii.data(), n, &grid);
-  // entries that will not be staged in the LDS (bind_grid) are gathered from L2: their runs in Morton order of the cells
-  if (have_grid && PT_GRID_LDS_CELLS(grid.cells.size()) + (size_t)grid.n_entries * 16 > walk_lds_room()) {
-    int mode = 2;
-#ifdef PT_DEV_KNOBS  // A/B only: PT_PAD_RUNS = 0 plain layout, 1 padded runs in Morton order, 2 Morton order (default), 3 padded runs
-    if (getenv("PT_PAD_RUNS")) mode = atoi(getenv("PT_PAD_RUNS"));
-#endif
-    if (mode) (void)ptgrid::morton_runs(&grid, mode != 2, mode != 3);
-  }
+  const bool have_grid = regular && build_grid(geom.data(), radii.data(), n, 3.0, &grid);
   const double t_grid = host_ms();
   c->setup_ms[PT_SETUP_SPHERES_SPLIT] = t_split - t_begin;
   c->setup_ms[PT_SETUP_SPHERES_BVH_BUILD] = t_bvh - t_split;
@@ -592,43 +646,13 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     c->have_bvh = true;
   }
   c->have_grid = false;
+  c->h_geom.clear(); c->h_radii.clear(); c->h_mat.clear();
   if (have_grid) {
-    const size_t n_cells_pad = (grid.cells.size() + 3u) & ~(size_t)3u;  // the kernels stage 16 B at a time
-    if (n_cells_pad > c->grid_cell_cap) {
-      if (c->d_grid_cells) PT_HIP(c, hipFree(c->d_grid_cells));
-      c->d_grid_cells = nullptr; c->grid_cell_cap = 0;
-      PT_HIP(c, hipMalloc(&c->d_grid_cells, n_cells_pad * sizeof(uint32_t)));
-      c->grid_cell_cap = n_cells_pad;
-    }
-    // + four entries of slack: a leaf round reads four consecutive entries whatever the cell's
-    // count (and lanes without a cell under test read, and discard, wherever their stale record points)
-    const size_t n_ent_pad = (size_t)grid.n_entries + 4u;
-    if (n_ent_pad > c->grid_entry_cap) {
-      if (c->d_grid_entries) PT_HIP(c, hipFree(c->d_grid_entries));
-      if (c->d_grid_index) PT_HIP(c, hipFree(c->d_grid_index));
-      if (c->d_grid_mat) PT_HIP(c, hipFree(c->d_grid_mat));
-      c->d_grid_entries = nullptr; c->d_grid_index = nullptr; c->d_grid_mat = nullptr; c->grid_entry_cap = 0;
-      PT_HIP(c, hipMalloc(&c->d_grid_entries, n_ent_pad * 16));
-      PT_HIP(c, hipMalloc(&c->d_grid_index, n_ent_pad * sizeof(uint32_t)));
-      PT_HIP(c, hipMalloc(&c->d_grid_mat, n_ent_pad * sizeof(PtMatRec)));
-      c->grid_entry_cap = n_ent_pad;
-    }
-    PT_HIP(c, hipMemset(c->d_grid_cells, 0, n_cells_pad * sizeof(uint32_t)));
-    PT_HIP(c, hipMemcpy(c->d_grid_cells, grid.cells.data(), grid.cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemset(c->d_grid_entries, 0, n_ent_pad * 16));
-    PT_HIP(c, hipMemcpy(c->d_grid_entries, grid.entries.data(), (size_t)grid.n_entries * 16, hipMemcpyHostToDevice));
-    PT_HIP(c, hipMemset(c->d_grid_index, 0xff, n_ent_pad * sizeof(uint32_t)));
-    PT_HIP(c, hipMemcpy(c->d_grid_index, grid.entry_index.data(), (size_t)grid.n_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
-    {
-      std::vector<PtMatRec> sm(n_ent_pad);
-      for (size_t k = 0; k < (size_t)grid.n_entries; k++) sm[k] = grid.entry_index[k] < n ? mat[grid.entry_index[k]] : PtMatRec{};
-      PT_HIP(c, hipMemcpy(c->d_grid_mat, sm.data(), sm.size() * sizeof(PtMatRec), hipMemcpyHostToDevice));
-    }
-    grid.cells.clear(); grid.cells.shrink_to_fit();
-    grid.entries.clear(); grid.entries.shrink_to_fit();
-    grid.entry_index.clear(); grid.entry_index.shrink_to_fit();
-    c->grid = grid;
-    c->have_grid = true;
+    int rc = install_grid(c, grid, mat.data(), n);
+    if (rc != PT_OK) return rc;
+    c->h_geom.assign(geom.begin(), geom.begin() + 4 * (size_t)n);
+    c->h_radii = radii;
+    c->h_mat = mat;
   }
   c->n_spheres = n;
   c->epoch++;
@@ -1811,8 +1835,56 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
   return fail(c, PT_ERR_INVALID, "pt_set_option: unknown key %d", key);
 }
 
+namespace {
+
+// FIT THE GRID TO THE VIEW.  pt_set_spheres builds the grid for rays that start within 2 s0 of the scene's middle (d_near =
+// 3 s0): it does not know where the camera will stand.  The margin every sphere is registered with grows with d_near^2 (the
+// cancellation in the shader's own `c` term: pt_grid.hpp), so a scene whose rays all start close by pays for rays that never
+// come — config 5, camera at 1.2 s0: 2.5 s0 instead of 3 is +2.8 % (profiles/r05_ab_runs.txt) — and a camera beyond 2 s0 turns
+// every primary ray into a far ray (exact, but tested against the whole list).  pt_tune — the synchronous set-up call that fits
+// the context to scene AND uniforms — rebuilds the grid for the smallest of a few factors that covers the camera (and its
+// lens); bounce rays start on spheres, within s0, or on an always-tested giant anywhere: those from beyond take the far path
+// as before.  A matter of speed only: the image bits do not depend on d_near.  Not after a launch has been captured into
+// a caller's hipGraph (its arguments hold the old grid's numbers).
+int fit_grid_to_view(pt_ctx* c) {
+  if (!c->have_grid || !c->have_params || c->captured || c->h_geom.empty()) return PT_OK;
+  const PtParams& p = c->params;
+  double rho = 0.0, reach = 0.0;
+  for (int k = 0; k < 3; k++) {
+    const double dk = (double)p.camera_origin[k] - (double)c->grid.c0[k];
+    rho += dk * dk;
+    reach += std::fabs((double)p.lens_radius) * (std::fabs((double)p.u[k]) + std::fabs((double)p.v[k]));
+  }
+  rho = std::sqrt(rho) + reach;
+  if (!std::isfinite(rho)) return PT_OK;
+  const double need = ((rho / 0.9999 + (double)c->grid.s0) / (double)c->grid.s0) * 1.01;
+  static const double kFactors[] = {2.5, 3.0, 4.0, 5.5, 8.0};
+  double factor = kFactors[4];  // (a camera farther out than that: its rays take the far path, as any camera beyond 2 s0 did)
+  for (double f : kFactors) if (f >= need) { factor = f; break; }
+#ifdef PT_DEV_KNOBS
+  if (getenv("PT_GRID_DNEAR")) return PT_OK;  // (the A/B build's own factor stands)
+#endif
+  if (std::fabs(factor - (double)c->grid.near_factor) < 1e-6) return PT_OK;
+  ptgrid::Grid grid;
+  const uint32_t n = (uint32_t)c->h_radii.size();
+  if (!build_grid(c->h_geom.data(), c->h_radii.data(), n, factor, &grid)) return PT_OK;  // (no grid for that factor: the one in place stays)
+  PT_HIP(c, hipSetDevice(c->device));
+  PT_HIP(c, hipStreamSynchronize(c->stream));  // launches in flight read the grid in place
+  int rc = install_grid(c, grid, c->h_mat.data(), n);
+  if (rc != PT_OK) return rc;
+  c->epoch++;
+  list_paths(c);  // (which kernels the grid can feed, and whether PT_GEOM_AUTO has anything to measure, follow its size)
+  return PT_OK;
+}
+
+} // namespace
+
 PT_API int pt_tune(pt_ctx* c, uint32_t n_passes) {
   if (!c || n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_tune: bad argument");
+  if (c->have_spheres) {
+    int rc = fit_grid_to_view(c);
+    if (rc != PT_OK) return rc;
+  }
   if (c->geom_policy != PT_GEOM_AUTO || !c->have_spheres || c->n_trials < 2) return PT_OK; // nothing to decide
   c->geom_tuned = 0;
   c->trial_state = 0;

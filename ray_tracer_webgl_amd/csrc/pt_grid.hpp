@@ -97,6 +97,7 @@ struct Grid {
   float c0[3] = {0, 0, 0};
   float s0 = 0, rmin = 0, rmax = 0;
   float d_near = 0;   // rays with |o - c0|_2 + s0 <= d_near may walk the cells
+  float near_factor = 3.0f;  // d_near / s0 as asked for
   float delta_g = 0;  // registration inflation
   // what the kernel's entry test uses (made here so that the kernel launch and the host emulation
   // of tests/test_grid.py read the same numbers): near rays are those with |o - c0|^2 <= r2_near
@@ -137,7 +138,10 @@ inline double delta_of(double rmin, double rmax, double D) {
 // geom: n x {cx, cy, cz, r*r} as the list kernels read it; radius: n signed radii; all finite
 // (the caller only builds for scenes it classified as regular).  Returns false when a grid
 // would be useless or cannot be represented; the other paths are used then.
-inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out) {
+// near_factor: rays that start within (near_factor - 1) s0 of the scene's middle walk the cells (d_near = near_factor s0).
+// A matter of speed only: rays from farther away are handled exactly, slowly (pt_grid_walk.hpp), and the margin's first
+// term grows with d_near^2.  3 unless the caller knows where the rays come from (pt_api.hip fit_grid_to_view).
+inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out, double near_factor = 3.0) {
   *out = Grid();
   if (n < 16) return false;
   // ---- far-out giants (same rule as pt_bvh.hpp) ---------------------------------------------
@@ -225,11 +229,11 @@ inline bool build(const float* geom, const float* radius, uint32_t n, Grid* out)
     }
     g.s0 = round_up(s0 * (1.0 + 1e-6));
     g.rmin = round_down(rmin); g.rmax = round_up(rmax);
-    double near_factor = 3.0;  // rays that start within (near_factor - 1) s0 of the scene's middle walk the cells
 #ifdef PT_DEV_KNOBS
     if (const char* e = std::getenv("PT_GRID_DNEAR")) { const double v = std::atof(e); if (v >= 2.0 && v <= 6.0) near_factor = v; }
 #endif
     g.d_near = round_up(near_factor * (double)g.s0);
+    g.near_factor = (float)near_factor;
     // ---- resolution --------------------------------------------------------------------------
     double diag = 0.0;
     uint32_t n_sum = 0;

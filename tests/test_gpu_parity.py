@@ -1449,6 +1449,45 @@ def test_every_launched_wave_is_resident(which):
     assert len(np.unique(where)) == k, "%d waves in %d wave slots" % (k, len(np.unique(where)))
 
 
+def test_tune_fits_the_grid_to_the_view(ora):
+    """pt_set_spheres builds the grid for rays that start within 2 s0 of the scene's middle (it does not know the camera);
+    pt_tune, the set-up call that knows scene AND uniforms, rebuilds it for the smallest margin class that covers the camera
+    (pt_api.hip fit_grid_to_view): fewer entries for a camera close by, a grid that still serves a camera far out (whose
+    rays would otherwise all be tested against the whole list).  Speed only — the image is the oracle's either way."""
+    from ray_tracer_webgl_amd import _lib
+
+    lib = _lib.load()
+    sph = scenes.field_spheres(1500)
+    entries = {}
+    for name, cam in (("close", (60.0, 15.0, 60.0)), ("far out", (190.0, 60.0, 190.0))):
+        p = scenes._base_params(2, 8)
+        scenes._look_at(lib, p, 96, 54, cam, (0.0, 8.0, 0.0), 40.0, 0.0, 80.0)
+        sc = scenes.Scene("field", sph, p, 2, "field")
+        ref, seg = ora.render(sc.spheres, sc.params, 2)
+        t = PathTracer(96, 54)
+        t.set_geometry_path(abi.PT_GEOM_GRID)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.reserve_passes(2)
+        built = t.stats().grid_entries
+        if name == "close":  # (the camera far out is only rendered on the fitted grid: on the other every primary ray walks the list)
+            t.render_passes(2)
+            assert_bit_equal(t.accum(), ref, "grid as built")
+            assert t.stats().segments == seg
+        t.tune(2)
+        fitted = t.stats().grid_entries
+        t.reset()
+        t.render_passes(2)
+        assert_bit_equal(t.accum(), ref, "grid fitted to the %s camera" % name)
+        assert t.stats().segments == seg and t.stats().geometry_path == abi.PT_GEOM_GRID
+        entries[name] = (built, fitted)
+        t.tune(2)  # a second call finds the grid in place
+        assert t.stats().grid_entries == fitted
+        t.close()
+    assert entries["close"][1] < entries["close"][0], entries      # a smaller d_near, smaller margins
+    assert entries["far out"][1] > entries["far out"][0], entries  # a larger one
+
+
 def test_plain_c_multi_gpu_example_gathers_the_single_gpu_frame(tmp_path, ora):
     """examples/render_bands.c (VERDICT r4 "missing" #2): multi-GPU rendering from ONE plain-C host process, as the
     reference's Rust host would drive it — one pt_ctx per rank with its interleaved row bands (PtParams.band_*), one
