@@ -128,7 +128,8 @@ class PathTracer:
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_RUSSIAN_ROULETTE, int(min_depth)))
 
     def tune(self, n_passes):
-        """Settle PT_GEOM_AUTO now (one cold + one untimed launch of n_passes passes per usable
+        """Fit the context to scene and uniforms: the grid is rebuilt for the margin class that covers the camera
+        (speed only), then PT_GEOM_AUTO is settled now (one cold + one untimed launch of n_passes passes per usable
         path); clears the accumulation."""
         self._check(self.lib.pt_tune(self._ctx, int(n_passes)))
         if self.accum_tensor is not None:
