@@ -117,6 +117,7 @@ int main(int argc, char** argv) {
     PT(pt_set_spheres(ctx[r], spheres, n_spheres), ctx[r]);    /* every rank uploads the same scene: no broadcast needed */
     PT(pt_set_params(ctx[r], &q), ctx[r]);
     PT(pt_reserve_passes(ctx[r], n_passes), ctx[r]);
+    PT(pt_tune(ctx[r], n_passes < 8u ? n_passes : 8u), ctx[r]);  /* set-up: fits the grid to the camera, settles PT_GEOM_AUTO (synchronous; the same choice on every rank: same scene, same camera) */
     HIP(hipMalloc((void**)&send[r], slot_floats * sizeof(float)));
     HIP(hipMemsetAsync(send[r], 0, slot_floats * sizeof(float), stream[r]));   /* rows beyond rows_of[r] stay 0 */
     HIP(hipMalloc((void**)&recv[r], (size_t)ranks * slot_floats * sizeof(float)));
