@@ -464,7 +464,7 @@ def main():
                  "set_params_ms": round((tfc - tfb) * 1e3, 2), "reserve_passes_ms": round((tf1 - tfc) * 1e3, 2)},
                 **setup_times(pt)),
             "note": "context (PathTracer: pt_create + torch buffer + stream binding; in a fresh process most of pt_create is the HIP runtime coming up and the code "
-                    "object loading: a second context takes 3 ms, tools/cold_start.py) + scene upload + structure builds + workspace (%d slabs); pt_tune (one cold and one measured %d-pass launch per "
+                    "object loading: a second context takes 3 ms, tools/cold_start.py) + scene upload + structure builds + workspace (%d slabs); pt_tune (the grid rebuilt for the margin class that covers the camera; one cold and one measured %d-pass launch per "
                     "geometry path whose outcome is open: none on an even grid); the first %d-spp frame with no tile-order feedback from a launch of its own shape (rank 0's share)"
                     % (reserve, tune_passes, k_frame * spp_step),
         }
