@@ -16,6 +16,7 @@ grid = len(sys.argv) > 3 and sys.argv[3] == "grid"
 force_small = len(sys.argv) > 3 and sys.argv[3] == "small"  # force the small-list kernels on lists of 1 .. 16 spheres
 used = 0
 bad = 0
+refitted = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500, 4000] if bvh else [1, 2, 5, 9, 17, 40, 130, 400]))
@@ -42,7 +43,21 @@ for seed in range(lo, hi):
             sc.spheres["center"] += np.float32(rng.choice([50.0, 3000.0]))
             sc.params.camera_origin[0] += float(sc.spheres["center"][0][0]) * 0  # camera stays: distant views
     from ray_tracer_webgl_amd.tracer import PathTracer
-    t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=path)
+    if grid and seed % 2 == 1:
+        # ... with the grid fitted to the scene's camera first (pt_tune: another margin class, another set of entries)
+        t = PathTracer(sc.params.width, sc.params.height)
+        t.set_geometry_path(path)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.reserve_passes(passes)
+        before = t.stats().grid_entries
+        t.tune(1)
+        refitted += int(t.stats().grid_entries != before)
+        t.set_params(sc.params)
+        t.render_passes(passes)
+        got = t.accum()
+    else:
+        t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, passes + 1)), geometry_path=path)
     used += int(t.stats().geometry_path == path or path == 0)
     ref, seg = oracle.render(sc.spheres, sc.params, passes)
     ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and t.stats().segments == seg
@@ -52,4 +67,4 @@ for seed in range(lo, hi):
     t.close()
     if seed % 50 == 0:
         print("seed", seed, "ok so far, bad =", bad, flush=True)
-print("done", lo, hi, "bad =", bad, "forced path really used:", used)
+print("done", lo, hi, "bad =", bad, "forced path really used:", used, "grids refitted by pt_tune:", refitted)
