@@ -488,6 +488,7 @@ bool build_grid(const float* geom, const float* radii, uint32_t n, double near_f
 
 // upload a grid (the caller has made sure that nothing in flight reads the previous one); empties the host arrays of `grid`
 int install_grid(pt_ctx* c, ptgrid::Grid& grid, const PtMatRec* mat, uint32_t n) {
+  c->have_grid = false;  // (until everything below has succeeded: a failed allocation must not leave a grid that points nowhere)
   const size_t n_cells_pad = (grid.cells.size() + 3u) & ~(size_t)3u;  // the kernels stage 16 B at a time
   if (n_cells_pad > c->grid_cell_cap) {
     if (c->d_grid_cells) PT_HIP(c, hipFree(c->d_grid_cells));
@@ -1871,10 +1872,9 @@ int fit_grid_to_view(pt_ctx* c) {
   PT_HIP(c, hipSetDevice(c->device));
   PT_HIP(c, hipStreamSynchronize(c->stream));  // launches in flight read the grid in place
   int rc = install_grid(c, grid, c->h_mat.data(), n);
-  if (rc != PT_OK) return rc;
   c->epoch++;
-  list_paths(c);  // (which kernels the grid can feed, and whether PT_GEOM_AUTO has anything to measure, follow its size)
-  return PT_OK;
+  list_paths(c);  // (which kernels the grid can feed, and whether PT_GEOM_AUTO has anything to measure, follow its size — or its absence, had the upload failed)
+  return rc;
 }
 
 } // namespace
