@@ -34,6 +34,8 @@ pt.set_spheres(sc.spheres)
 pt.set_params(p)
 pt.reserve_passes(passes)
 pt.set_geometry_path(path)
+pt.tune(1)  # (the grid fitted to the camera, as bench.py has it)
+pt.set_params(p)
 for _ in range(2):
     pt.reset()
     pt.render_passes(passes)
