@@ -651,8 +651,10 @@ def main():
 
         # a prior rocprofv3 PMC profile of the same kernel, config and launch shape, if one is committed
         # (profiles/pmc_traffic.json: one record per kernel + config, written by profiles/summarize.py)
+        identity = build_identity()
         prior = prior_pmc_record(kernel_name, args.config, args.spp_per_pass, ppl) if world == 1 else None
-        counters = counters_of(prior)
+        counters = counters_of(prior, avg_ms, identity)
+        prior = fresh(prior, identity)  # (a record of another build: no traffic figure either)
         roofline = {
             "kernel": kernel_name,
             "geometry_path": abi.GEOM_NAMES.get(st.geometry_path, "?") + (" (autotuned)" if st.geometry_tuned else ""),
@@ -782,6 +784,7 @@ def main():
             "roofline": roofline,
             "list_walk": list_walk,
             "cpu_baseline": cpu,
+            "build": identity,
         }
         if cpu:
             out["gpu_over_cpu"] = round(mrays / cpu["value"], 1) if cpu["value"] else None
@@ -810,30 +813,62 @@ def prior_pmc_record(kernel, config, spp_per_pass, passes_per_launch):
     return None
 
 
-def counters_of(prior):
+def build_identity():
+    from ray_tracer_webgl_amd import _lib
+
+    return _lib.build_identity()
+
+
+def counters_of(prior, this_kernel_ms=None, identity=None):
     """Counter-derived figures of a PRIOR profile record (profiles/summarize.py wrote it from the PMC passes):
          valu_issue_frac  = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
          lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
-         fp32_flop_frac   = (2 FMA + MUL) x 64 x lane_utilisation / kernel time / peak"""
+         fp32_flop_frac   = (2 FMA + MUL + ADD) x 64 x lane_utilisation / kernel time / peak
+    A record is only as good as the build it was collected on: it carries the sha256 of the sources of that build
+    (`csrc_sha256`, _lib.build_identity), and a record of ANOTHER build — or of none: the records of rounds 1-5 — is refused:
+    `stale` true, no figures.  `prior_kernel_ms / this_run_kernel_ms` is printed either way (HIP events of this run against
+    the profiler's kernel trace of the record)."""
     if not prior:
         return None
+    identity = identity or build_identity()
+    ratio = round(prior["kernel_ms"] / this_kernel_ms, 4) if (prior.get("kernel_ms") and this_kernel_ms) else None
+    head = {
+        "source": "PRIOR profile %s (rocprofv3 --pmc, same kernel and launch shape; not this run)" % prior.get("profile", "profiles/pmc_traffic.json"),
+        "record_csrc_sha256": prior.get("csrc_sha256"),
+        "this_build_csrc_sha256": identity["csrc_sha256"],
+        "kernel_ms": prior.get("kernel_ms"),
+        "this_run_kernel_ms": round(this_kernel_ms, 4) if this_kernel_ms else None,
+        "prior_over_this_run_kernel_ms": ratio,
+    }
+    if prior.get("csrc_sha256") != identity["csrc_sha256"]:
+        head["stale"] = True
+        head["note"] = ("the record was collected on another build of the kernels (or carries no build identity): its figures are "
+                        "not this library's and are not shown; re-collect with profiles/collect.sh")
+        return head
+    head["stale"] = False
     lu = None
     if prior.get("sq_thread_cycles_valu") and prior.get("sq_active_inst_valu"):
         lu = prior["sq_thread_cycles_valu"] / (64.0 * prior["sq_active_inst_valu"])
     ff32 = None
     if lu and prior.get("kernel_ms") and prior.get("sq_insts_valu_fma_f32") is not None:
-        flop = (2.0 * prior["sq_insts_valu_fma_f32"] + prior.get("sq_insts_valu_mul_f32", 0.0)) * 64.0 * lu
+        flop = (2.0 * prior["sq_insts_valu_fma_f32"] + prior.get("sq_insts_valu_mul_f32", 0.0) + prior.get("sq_insts_valu_add_f32", 0.0)) * 64.0 * lu
         ff32 = flop / (prior["kernel_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS
-    return {
-        "source": "PRIOR profile %s (rocprofv3 --pmc, same kernel and launch shape; not this run)" % prior.get("profile", "profiles/pmc_traffic.json"),
-        "kernel_ms": prior.get("kernel_ms"),
+    head.update({
         "valu_issue_frac": round(prior["valu_issue_frac"], 4) if prior.get("valu_issue_frac") else None,
         "cycles_per_valu_per_simd": round(2.0 / prior["valu_issue_frac"], 3) if prior.get("valu_issue_frac") else None,
         "lane_utilisation": round(lu, 4) if lu else None,
         "fp32_flop_frac": round(ff32, 4) if ff32 else None,
+        "fp32_flop_frac_is": "(2 x FMA_F32 + MUL_F32 + ADD_F32 wave-instructions) x 64 x lane_utilisation / kernel time / %.1f TFLOP/s" % FP32_VALU_PEAK_TFLOPS,
         "salu_per_valu": round(prior["sq_insts_salu"] / prior["valu_insts_per_launch"], 3) if prior.get("sq_insts_salu") and prior.get("valu_insts_per_launch") else None,
         "lds_bank_conflict_frac": round(prior["sq_lds_bank_conflict"] / prior["sq_lds_idx_active"], 4) if prior.get("sq_lds_idx_active") else None,
-    }
+    })
+    return head
+
+
+def fresh(prior, identity=None):
+    """the record itself when it was collected on THIS build, else None (its traffic figure is as stale as its counters)"""
+    identity = identity or build_identity()
+    return prior if (prior and prior.get("csrc_sha256") == identity["csrc_sha256"]) else None
 
 
 def frame_loop_bench(args):
@@ -855,7 +890,9 @@ def frame_loop_bench(args):
     # a list kernel tests every sphere for every segment (static/shader.frag:175-196): 20 FLOP each, + ~150 per segment of scatter / RNG / camera
     flop = g["segments_per_launch"] * (FLOP_PER_SPHERE_TEST * g["n_spheres"] + FLOP_PER_SEGMENT_SHADE)
     achieved = flop / t_launch / 1e12 if t_launch > 0 else None
-    prior = prior_pmc_record(g["kernel"], "default", g["spp_per_pass"], g["passes_per_launch"])
+    identity = build_identity()
+    prior_any = prior_pmc_record(g["kernel"], "default", g["spp_per_pass"], g["passes_per_launch"])
+    prior = fresh(prior_any, identity)
     n_pix, k = g["pixels"], g["passes_per_launch"]
     # HBM bytes of ONE GROUP of frames as built: the trace kernel stores one 16-B slab entry per (pixel, frame); the blend kernel
     # reads them, reads the previous RGBA8 texture and writes the last two frames' textures and the canvas (src/webgl.rs:186-204)
@@ -880,7 +917,7 @@ def frame_loop_bench(args):
         "gray_s_of_the_kernel": round(g["segments_per_launch"] / t_launch / 1e9, 2) if t_launch > 0 else None,
         "traffic": prior.get("pt_trace_kernel_hbm_bytes_per_launch") if prior else None,
         "traffic_source": ("PRIOR profile %s (rocprofv3 --pmc WRITE_SIZE + 2*FETCH_SIZE of the group's trace launch)" % prior.get("profile")) if prior else None,
-        "counters": counters_of(prior),
+        "counters": counters_of(prior_any, g["avg_launch_ms"], identity),
         "hbm": {
             "algorithmic_bytes_per_group": group_bytes,
             "achieved": round(sum(group_bytes.values()) / (group_ms * 1e-3) / 1e9, 1) if group_ms else None,
@@ -889,6 +926,7 @@ def frame_loop_bench(args):
             "note": "all three kernels of a group (trace, blend, advance) over the group's device time: the loop is not HBM-bound either",
         },
     }
+    out["build"] = identity
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = frame_loop_cpu_baseline(out)
         if out["cpu_baseline"] and out["cpu_baseline"]["value"]:

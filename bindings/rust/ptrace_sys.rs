@@ -34,6 +34,8 @@ pub struct PtParams {            // == uniform block, static/shader.frag:79-99
 #[link(name = "ptrace")]
 extern "C" {
     pub fn pt_create(out: *mut *mut PtCtx, device: c_int, width: u32, height: u32) -> c_int;
+    // for a host that brings its own hipStream_t: the context never creates a stream (an HSA queue) of its own
+    pub fn pt_create_on_stream(out: *mut *mut PtCtx, device: c_int, width: u32, height: u32, hip_stream: *mut c_void) -> c_int;
     pub fn pt_destroy(ctx: *mut PtCtx) -> c_int;
     pub fn pt_resize(ctx: *mut PtCtx, width: u32, height: u32) -> c_int;
     pub fn pt_set_spheres(ctx: *mut PtCtx, spheres: *const PtSphere, n: u32) -> c_int;
@@ -53,6 +55,10 @@ extern "C" {
     pub fn pt_set_stream(ctx: *mut PtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn pt_set_option(ctx: *mut PtCtx, key: c_int, value: c_int) -> c_int;
     pub fn pt_tune(ctx: *mut PtCtx, n_passes: u32) -> c_int;
+    // the camera moves every tick (State::update_position, src/state.rs:411-441): does the grid of a large scene still fit
+    // it (0 yes / 1 no: refit now / 2 looser than needed), and the rebuild for the margin class the camera needs
+    pub fn pt_grid_fit(ctx: *mut PtCtx) -> c_int;
+    pub fn pt_refit_grid(ctx: *mut PtCtx, only_if_stale: c_int) -> c_int;
     // the reference's frame on device-resident textures: webgl::render, src/webgl.rs:180-205
     pub fn pt_clear_textures(ctx: *mut PtCtx) -> c_int;
     pub fn pt_render_frame(ctx: *mut PtCtx, even_odd_count: u32) -> c_int;
@@ -75,6 +81,8 @@ pub const PT_OPT_RUSSIAN_ROULETTE: c_int = 5;   // opt-in, 0 = off: the referenc
 //     state::update_render_globals(&mut state);
 //     let p = PtParams::from_state(&state, now);            // uniforms.run_setters(now)
 //     pt_set_params(ctx, &p);
+//     if pt_grid_fit(ctx) == 1 { pt_refit_grid(ctx, 0); }   // scenes of hundreds of spheres: the camera has left the region the
+//                                                           // grid was fitted to (host arithmetic; 0 for the reference's 9 spheres)
 //     pt_render_frame(ctx, state.even_odd_count);           // webgl::render: trace + blend into the ping-pong textures
 //     if should_save { pt_read_canvas(ctx, pixels.as_mut_ptr()); }
 // A run of ticks with nothing else happening (no input: no key held; should_average on — without it only the

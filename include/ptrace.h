@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5 /* 5: PtStats grew (grid_fit_stale, grid_near_factor, far_rays); pt_refit_grid, pt_create_on_stream;
+                            pt_tune refits the grid; the dev header's pt_debug_wave_log writes four words per wave */
 
 /* ---- error codes (returned by every int function; 0 = success) ------------------------------ */
 enum {
@@ -209,13 +210,23 @@ typedef struct PtStats {
   uint32_t grid_cells[3];   /* uniform grid of the current scene (0 = none): cells per axis,          */
   uint32_t grid_entries;    /* entries (copies of a sphere, one per cell it is registered in + padding) */
   uint32_t grid_always;     /* spheres tested for every ray                                            */
-  uint32_t _pad;
+  uint32_t grid_fit_stale;  /* does the grid still fit the camera of the last pt_set_params?  0: yes (or no grid / not the
+                               path in use).  1: NO — the camera stands outside the region whose rays walk the cells, so every
+                               primary ray takes the far path (exact, but tested against the WHOLE list): call pt_refit_grid
+                               (or pt_tune).  2: looser than needed — a smaller margin class would cover the camera (a few
+                               per cent of speed, never a cliff).  The reference moves its camera every tick
+                               (src/state.rs:411-441); pt_set_params only sets this flag, it never rebuilds.       */
   /* executed work of the walk kernels since the last reset, filled when PT_OPT_COUNT_WORK is on:
    * [0] walk iterations (node steps / cell steps, wave-level)   [1] lanes active in them (sum)
    * [2] leaf rounds (four literal tests per lane)               [3] lanes active in them
    * [4] exact evaluations (sqrt + division), wave-level         [5] lanes active in them
    * [6] wave steps                                              [7] lanes carried over (sum)   */
   uint64_t work[8];
+  float grid_near_factor;   /* d_near / s0 the grid in place was built for (3 from pt_set_spheres; pt_tune / pt_refit_grid
+                               choose among 2.5 / 3 / 4 / 5.5 / 8); 0 = no grid                                        */
+  float grid_need_factor;   /* the smallest of those classes that covers the current camera and its lens           */
+  uint64_t far_rays;        /* ray segments since the last reset that reached the grid from OUTSIDE its near region and
+                               were therefore tested against the whole list (grid walk only; ~0 on a fitted grid)     */
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -224,6 +235,11 @@ typedef struct pt_ctx pt_ctx;
  * (src/webgl.rs:66-80, :82-123, :153-167).  Allocates the fp32 linear accumulation buffer for
  * a w*h image on HIP device `device` and a stream.  Caller frees with pt_destroy. */
 int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height);
+/* Same, for a host that brings its own hipStream_t (a torch stream, an engine's render queue): the context runs on it
+ * from the start and never creates a stream — hence an HSA queue, ~80-150 ms when it is the process's first — of its own.
+ * `hip_stream` as in pt_set_stream (PT_STREAM_LEGACY names the default stream); NULL behaves like pt_create.  A later
+ * pt_set_stream(ctx, NULL) on such a context creates the own stream then. */
+int pt_create_on_stream(pt_ctx** out, int device, uint32_t width, uint32_t height, void* hip_stream);
 int pt_destroy(pt_ctx* ctx);
 /* resize path, src/state.rs:364-398: reallocates buffers and clears the accumulation */
 int pt_resize(pt_ctx* ctx, uint32_t width, uint32_t height);
@@ -328,6 +344,17 @@ int pt_set_option(pt_ctx* ctx, int key, int value);
  * Call it before capturing pt_render* into a hipGraph: a captured launch keeps the path it was
  * captured with (no measuring happens while a stream is capturing). */
 int pt_tune(pt_ctx* ctx, uint32_t n_passes);
+/* Part (i) of pt_tune alone: rebuild the grid for the margin class the CURRENT camera needs (PtStats.grid_need_factor) when
+ * it differs from the one in place; nothing else — no measuring launches, accumulation, textures and statistics untouched.
+ * What a frame loop calls when PtStats.grid_fit_stale (or pt_grid_fit(ctx)) says so: the reference's camera moves every tick
+ * (State::update_position, src/state.rs:411-441), and a camera that has left the region the grid was fitted to sends every
+ * primary ray down the far path.  Synchronises the stream when it rebuilds (~2 ms of host work for 10 000 spheres); a no-op
+ * (PT_OK) when the grid fits, when there is none, when another geometry path is forced, and once a launch has been
+ * captured into a caller's hipGraph (its arguments hold the old grid's numbers; pt_render_frames' own graphs are
+ * re-captured by themselves).  `only_if_stale` != 0: rebuild only for state 1 (too small), keep a looser grid. */
+int pt_refit_grid(pt_ctx* ctx, int only_if_stale);
+/* PtStats.grid_fit_stale without the synchronisation pt_get_stats implies: 0 / 1 / 2 as there, < 0 on error.  Host arithmetic only. */
+int pt_grid_fit(pt_ctx* ctx);
 /* The hierarchy pt_set_spheres builds for PT_GEOM_BVH, on the host (no device needed; tests
  * check its invariants): nodes = 8 floats each {lo.xyz, bits(skip), hi.xyz, bits(first slot of
  * the leaf | 0xffffffff)}, slots = 4 floats each {cx, cy, cz, r*r}, slot_index = original sphere

@@ -137,7 +137,10 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
                        % (cfg_key, bench.get("config", {}).get("workload", "?"), ppl, spp_pass),
            "spp_per_pass": spp_pass, "passes_per_launch": ppl, "hbm_bytes_per_pass": int(traffic / ppl),
            "profile": "profiles/" + os.path.basename(os.path.normpath(d)).replace("prof_", "") + "_summary.txt",
-           "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"]}
+           "write_size_kib": pm["WRITE_SIZE"], "fetch_size_kib": pm["FETCH_SIZE"],
+           # the build the counters belong to (the profiled bench line says what it ran on: ray_tracer_webgl_amd/_lib.py
+           # build_identity); bench.py attaches the record only to lines of the same build
+           "csrc_sha256": (bench.get("build") or {}).get("csrc_sha256"), "lib_sha256": (bench.get("build") or {}).get("lib_sha256")}
     # what the kernel actually issued (the hierarchy walk skips most of the algorithmic tests):
     # wave-level VALU instructions per launch and the share of the chip's VALU issue slots they
     # fill (one wave64 instruction occupies a SIMD's 32 lanes for 2 cycles; GRBM_GUI_ACTIVE is

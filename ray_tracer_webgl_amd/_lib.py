@@ -19,6 +19,7 @@ _vp = C.c_void_p
 _ctx = C.c_void_p
 SIGNATURES = {
     "pt_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_uint32, C.c_uint32]),
+    "pt_create_on_stream": (C.c_int, [C.POINTER(_ctx), C.c_int, C.c_uint32, C.c_uint32, _vp]),
     "pt_destroy": (C.c_int, [_ctx]),
     "pt_resize": (C.c_int, [_ctx, C.c_uint32, C.c_uint32]),
     "pt_set_spheres": (C.c_int, [_ctx, C.POINTER(abi.PtSphere), C.c_uint32]),
@@ -45,6 +46,8 @@ SIGNATURES = {
     "pt_get_stats": (C.c_int, [_ctx, C.POINTER(abi.PtStats)]),
     "pt_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "pt_tune": (C.c_int, [_ctx, C.c_uint32]),
+    "pt_refit_grid": (C.c_int, [_ctx, C.c_int]),
+    "pt_grid_fit": (C.c_int, [_ctx]),
     "pt_build_bvh": (C.c_int, [C.POINTER(abi.PtSphere), C.c_uint32, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp,
                                _vp, C.c_size_t, C.POINTER(C.c_float), _vp, C.c_size_t]),
     "pt_build_grid": (C.c_int, [C.POINTER(abi.PtSphere), C.c_uint32, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, C.c_size_t,
@@ -142,7 +145,7 @@ def _share_torch_hip_runtime(lib_path):
     try:
         wanted = [n for n in _elf_dynamic_strings(lib_path, (1,)) if n.startswith("libamdhip64.so")]
         offered = _elf_dynamic_strings(path, (14,))
-    except (OSError, ValueError, IndexError):
+    except Exception:  # (struct.error on a truncated or odd ELF is none of OSError / ValueError / IndexError: no match, never an abort)
         return
     if not wanted or not offered or offered[0] != wanted[0]:
         return  # another ROCm major (or an unreadable file): leave it alone
@@ -150,6 +153,32 @@ def _share_torch_hip_runtime(lib_path):
         C.CDLL(path, mode=C.RTLD_GLOBAL)
     except OSError:
         pass  # (an unusable copy: the system runtime serves libptrace.so, and use_torch will say what is wrong)
+
+
+def build_identity():
+    """What the library in use was built from: sha256 over the kernel and host sources (csrc/*.hip, *.hpp, *.h, *.cpp, the
+    Makefile's flags, include/ptrace*.h: name and content, sorted) and, for the record, over the shared object itself.
+    profiles/summarize.py writes it into every counter record it derives from a profiled bench line and bench.py refuses
+    to attach a record of another build to a later line (a stale issue fraction would look like a measurement)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".hpp", ".h", ".cpp")) or f == "Makefile"]
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files += [os.path.join(inc, f) for f in ("ptrace.h", "ptrace_dev.h") if os.path.exists(os.path.join(inc, f))]
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    lib_path = os.environ.get("PT_LIB", LIB_PATH)
+    lib_sha = None
+    if os.path.exists(lib_path):
+        with open(lib_path, "rb") as f:
+            lib_sha = hashlib.sha256(f.read()).hexdigest()
+    return {"csrc_sha256": h.hexdigest(), "lib_sha256": lib_sha, "lib": os.path.relpath(lib_path, os.path.dirname(_HERE)),
+            "abi": abi.PT_ABI_VERSION}
 
 
 def load():

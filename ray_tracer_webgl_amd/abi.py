@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-PT_ABI_VERSION = 4
+PT_ABI_VERSION = 5
 
 PT_OK = 0
 PT_ERR_INVALID = -1
@@ -144,8 +144,11 @@ class PtStats(C.Structure):
         ("grid_cells", C.c_uint32 * 3),
         ("grid_entries", C.c_uint32),
         ("grid_always", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("grid_fit_stale", C.c_uint32),  # 0 fits / 1 camera outside the near region (far path: refit) / 2 looser than needed
         ("work", C.c_uint64 * 8),
+        ("grid_near_factor", C.c_float),
+        ("grid_need_factor", C.c_float),
+        ("far_rays", C.c_uint64),
     ]
 
 

@@ -21,12 +21,20 @@ from .tracer import PathTracer
 
 
 class FrameLoop:
-    def __init__(self, width, height, device=0, mode="reference"):
+    # frames a grid may stay LOOSER than the camera needs (PtStats.grid_fit_stale == 2: a few per cent of speed) before it
+    # is refitted; a grid that is too SMALL (== 1: every primary ray tested against the whole list) is refitted at once
+    LOOSE_FRAMES = 32
+
+    def __init__(self, width, height, device=0, mode="reference", host_spheres=None):
         assert mode in ("reference", "linear")
         self.mode = mode
         self.state = State(width, height)
+        if host_spheres is not None:  # another scene than State::default's nine spheres (abi.PtHostSphere records, f64 like src/glsl.rs:27-40)
+            self.state.set_spheres(host_spheres)
         self.tracer = PathTracer(width, height, device=device)
         self.tracer.set_spheres(self.state.spheres())  # set_geometry, once (src/lib.rs:57)
+        self.grid_refits = 0
+        self._loose = 0
         # two RGBA8 textures cleared to 0 (alpha 0 = "no data", shader.frag:391): in HBM, owned by the context
         self.tracer.clear_textures()
         self._canvas = None
@@ -48,6 +56,23 @@ class FrameLoop:
     def textures(self):
         return [self.tracer.read_texture(0), self.tracer.read_texture(1)]
 
+    def _keep_the_grid_fitted(self):
+        """The reference moves its camera every tick a key is held (State::update_position, src/state.rs:411-441); the grid
+        of a large scene is fitted to where rays START (pt_tune / pt_refit_grid).  After the tick's uniforms are up: a camera
+        that has left the fitted region gets a grid that serves it before the frame is traced (pt_refit_grid: ~2 ms of host
+        work for 10 000 spheres, the stream is drained), a grid looser than needed is tightened once the camera has stayed
+        inside for LOOSE_FRAMES frames.  Speed only: the frame's bits do not depend on the grid.  Scenes without a grid
+        (State::default's nine spheres) answer 0 from host arithmetic."""
+        fit = self.tracer.grid_fit()
+        if fit == 1 or (fit == 2 and self._loose + 1 >= self.LOOSE_FRAMES):
+            self.tracer.refit_grid()
+            self.grid_refits += 1
+            self._loose = 0
+        elif fit == 2:
+            self._loose += 1
+        else:
+            self._loose = 0
+
     def frame(self, now_ms, should_save=False):
         """One rAF tick.  Returns True when a frame was rendered."""
         st = self.state
@@ -61,6 +86,7 @@ class FrameLoop:
         p = st.to_params(now_ms)                    # uniforms.run_setters, :96
         if self.mode == "reference":
             self.tracer.set_params(p)
+            self._keep_the_grid_fitted()
             # webgl::render: previous frame = textures[(even_odd + 1) % 2] (src/webgl.rs:186-190), draw
             # to the canvas (:193-194) and, when averaging, to the other texture (:197-204)
             self.tracer.render_frame(v.even_odd_count)
@@ -68,6 +94,7 @@ class FrameLoop:
             if v.render_count <= 1:  # accumulation restarts after any camera change
                 self.tracer.reset()
             self.tracer.set_params(p)
+            self._keep_the_grid_fitted()
             self.tracer.render()
             self._canvas = self.tracer.resolve_rgba8(True)
         self.frames_rendered += 1
@@ -103,6 +130,7 @@ class FrameLoop:
         p.time_step = float(interval_ms)  # frame k: u_time = time + float(k) * interval (fp32, like the kernel's pass time)
         p.first_pass = 0
         self.tracer.set_params(p)
+        self._keep_the_grid_fitted()  # (before the series' graphs are captured: a refit re-captures them by itself)
         self.tracer.render_frames(v.even_odd_count, v.max_render_count, n)
         for _ in range(n - 1):                       # the host's copy of the counters follows
             st.update_render_globals()

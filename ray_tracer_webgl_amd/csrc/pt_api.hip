@@ -310,6 +310,29 @@ void list_paths(pt_ctx* c) {
   if (c->n_trials == 1) c->geom_tuned = c->trial_paths[0];  // nothing to measure
 }
 
+// The margin classes a grid is built for (d_near / s0: rays that start within (factor - 1) s0 of the scene's middle walk the
+// cells; pt_grid.hpp) and the smallest one that covers the camera of the current uniforms with its lens; 0 = no grid / no
+// uniforms / a camera that is not finite.  A camera farther out than the largest class gets the largest: its primary rays
+// take the far path as before (it sees the scene under a small angle: few of them reach the grid's box).
+constexpr double kNearFactors[] = {2.5, 3.0, 4.0, 5.5, 8.0, 12.0, 16.0};
+double view_need_factor(const pt_ctx* c) {
+  if (!c->have_grid || !c->have_params) return 0.0;
+  const PtParams& p = c->params;
+  double rho = 0.0, reach = 0.0;
+  for (int k = 0; k < 3; k++) {
+    const double dk = (double)p.camera_origin[k] - (double)c->grid.c0[k];
+    rho += dk * dk;
+    reach += std::fabs((double)p.lens_radius) * (std::fabs((double)p.u[k]) + std::fabs((double)p.v[k]));
+  }
+  rho = std::sqrt(rho) + reach;
+  if (!std::isfinite(rho)) return 0.0;
+  const double need = ((rho / 0.9999 + (double)c->grid.s0) / (double)c->grid.s0) * 1.01;
+  double factor = kNearFactors[sizeof kNearFactors / sizeof kNearFactors[0] - 1];
+  for (double f : kNearFactors) if (f >= need) { factor = f; break; }
+  return factor;
+}
+int grid_fit_state(const pt_ctx* c);  // (below, beside fit_grid_to_view)
+
 // LDS a walk kernel may fill with its staged scene: what is left beside a 1024-thread workgroup's parked path state
 constexpr size_t kWalkLdsMax = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
 constexpr size_t walk_lds_room() { return kWalkLdsMax - (size_t)PT_PARK_STRIDE * 4 * 1024; }
@@ -348,7 +371,9 @@ PT_API const char* pt_last_error(pt_ctx* ctx) {
   return ctx ? ctx->error.c_str() : g_create_error.c_str();
 }
 
-PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) {
+// pt_create / pt_create_on_stream: `caller_stream` non-NULL = the context runs on the caller's stream from the start and creates
+// none of its own (a stream is an HSA queue: 80-150 ms when it is the process's first)
+static int create_common(pt_ctx** out, int device, uint32_t width, uint32_t height, void* caller_stream) {
   if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
   *out = nullptr;
   if (width == 0 || height == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: empty image");
@@ -378,9 +403,13 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->max_lds = (int)prop.sharedMemPerBlock;
   const double t_device = host_ms();
-  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
-    return bail(e, "hipStreamCreateWithFlags");
-  c->stream = c->own_stream;
+  if (caller_stream) {
+    c->stream = (hipStream_t)caller_stream;
+  } else {
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
+      return bail(e, "hipStreamCreateWithFlags");
+    c->stream = c->own_stream;
+  }
   const double t_stream = host_ms();
   if ((e = hipMalloc(&c->d_counters, PT_CTR_ALLOC * sizeof(unsigned long long))) != hipSuccess)
     return bail(e, "hipMalloc(counters)");
@@ -424,6 +453,13 @@ PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) 
   return PT_OK;
 }
 
+PT_API int pt_create(pt_ctx** out, int device, uint32_t width, uint32_t height) {
+  return create_common(out, device, width, height, nullptr);
+}
+PT_API int pt_create_on_stream(pt_ctx** out, int device, uint32_t width, uint32_t height, void* hip_stream) {
+  return create_common(out, device, width, height, hip_stream);
+}
+
 PT_API int pt_destroy(pt_ctx* c) {
   if (!c) return PT_ERR_INVALID;
   (void)hipSetDevice(c->device);
@@ -465,6 +501,8 @@ PT_API int pt_set_stream(pt_ctx* c, void* hip_stream) {
   PT_HIP(c, hipStreamSynchronize(c->stream));
   int rc = fold_events(c);
   if (rc != PT_OK) return rc;
+  if (!hip_stream && !c->own_stream)  // a context made by pt_create_on_stream that now wants a stream of its own
+    PT_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   c->epoch++;
   return PT_OK;
@@ -1458,9 +1496,11 @@ bool same_view(const PtParams& a, const PtParams& b) {
 }
 int ensure_cost_order(pt_ctx* c, uint32_t n_frames) {
   if (c->params.samples_per_pixel < 4) {
-    if (c->order_probed) {  // back to the identity order: the costs are all zero after a probe, and the sort is stable
+    if (c->order_probed) {  // back to the identity order: what the order kernel writes when every cost is zero (a probe leaves them
+                            // zero, a pt_render_passes with cost feedback since then does not: cleared here)
       c->order_probed = false;
       c->tile_order_valid = false;
+      PT_HIP(c, hipMemsetAsync(c->d_tile_cost, 0, c->tile_cap * sizeof(uint32_t), c->stream));
     }
     return ensure_tile_order(c);
   }
@@ -1530,8 +1570,7 @@ PT_API int pt_render_frame(pt_ctx* c, uint32_t even_odd_count) {
   if (rc != PT_OK) return rc;
   rc = ensure_cost_order(c, 1);
   if (rc != PT_OK) return rc;
-  PT_HIP(c, hipMemsetAsync(&c->d_counters[PT_CTR_HEAD], 0, sizeof(unsigned long long), c->stream));
-  PT_HIP(c, zero_queue_heads(c, 2u));
+  PT_HIP(c, zero_queue_heads(c, F.L.A.queue_static));  // (the shared head, the groups' heads, or — statically dealt — none)
   rc = enqueue_frame(c, F, false);
   if (rc != PT_OK) return rc;
   c->launches++;
@@ -1790,10 +1829,14 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
   out->geometry_path = (uint32_t)c->geom_last;
   out->geometry_tuned = c->geom_tuned ? 1u : 0u;
   for (int k = 0; k < 8; k++) out->work[k] = ctr[PT_CTR_WORK + k];
+  out->far_rays = ctr[PT_CTR_FAR_RAYS];
   if (c->have_grid) {
     for (int k = 0; k < 3; k++) out->grid_cells[k] = c->grid.n[k];
     out->grid_entries = c->grid.n_entries;
     out->grid_always = c->grid.n_always;
+    out->grid_near_factor = c->grid.near_factor;
+    out->grid_need_factor = (float)view_need_factor(c);
+    out->grid_fit_stale = (uint32_t)grid_fit_state(c);
   }
   if (c->have_bvh) {
     out->bvh_nodes = c->bvh_n_nodes;
@@ -1843,46 +1886,70 @@ namespace {
 // cancellation in the shader's own `c` term: pt_grid.hpp), so a scene whose rays all start close by pays for rays that never
 // come — config 5, camera at 1.2 s0: 2.5 s0 instead of 3 is +2.8 % (profiles/r05_ab_runs.txt) — and a camera beyond 2 s0 turns
 // every primary ray into a far ray (exact, but tested against the whole list).  pt_tune — the synchronous set-up call that fits
-// the context to scene AND uniforms — rebuilds the grid for the smallest of a few factors that covers the camera (and its
-// lens); bounce rays start on spheres, within s0, or on an always-tested giant anywhere: those from beyond take the far path
-// as before.  A matter of speed only: the image bits do not depend on d_near.  Not after a launch has been captured into
-// a caller's hipGraph (its arguments hold the old grid's numbers).
-int fit_grid_to_view(pt_ctx* c) {
+// the context to scene AND uniforms — and pt_refit_grid — what a frame loop calls when the camera has moved — rebuild the grid
+// for the smallest of a few factors that covers the camera (and its lens); bounce rays start on spheres, within s0, or on an
+// always-tested giant anywhere: those from beyond take the far path as before.  A matter of speed only: the image bits do not
+// depend on d_near.  Not after a launch has been captured into a caller's hipGraph (its arguments hold the old grid's numbers).
+// Whether the grid in place still fits is host arithmetic on the uniforms (grid_fit_state: PtStats.grid_fit_stale,
+// pt_grid_fit): pt_set_params never rebuilds — a rebuild synchronises the stream and moves device buffers.
+bool grid_in_use(const pt_ctx* c) {  // can the grid be what the next launch walks?
+  if (!c->have_grid) return false;
+  if (c->geom_policy == PT_GEOM_GRID) return true;
+  return c->geom_policy == PT_GEOM_AUTO && (c->geom_tuned == 0 || c->geom_tuned == PT_GEOM_GRID);
+}
+
+int grid_fit_state(const pt_ctx* c) {
+  if (!grid_in_use(c) || !c->have_params) return 0;
+  const double need = view_need_factor(c);
+  if (need <= 0.0) return 0;
+  const double have = (double)c->grid.near_factor;
+  if (have < need - 1e-6) return 1;  // the camera stands outside the near region: every primary ray takes the far path
+  return have > need + 1e-6 ? 2 : 0;
+}
+
+// policy: 0 = rebuild whenever another class fits better, 1 = only when the class in place is too SMALL, 2 = pt_tune (like 0,
+// and whatever path PT_GEOM_AUTO had settled on: the measurement that follows decides anew)
+int fit_grid_to_view(pt_ctx* c, int policy) {
   if (!c->have_grid || !c->have_params || c->captured || c->h_geom.empty()) return PT_OK;
-  const PtParams& p = c->params;
-  double rho = 0.0, reach = 0.0;
-  for (int k = 0; k < 3; k++) {
-    const double dk = (double)p.camera_origin[k] - (double)c->grid.c0[k];
-    rho += dk * dk;
-    reach += std::fabs((double)p.lens_radius) * (std::fabs((double)p.u[k]) + std::fabs((double)p.v[k]));
-  }
-  rho = std::sqrt(rho) + reach;
-  if (!std::isfinite(rho)) return PT_OK;
-  const double need = ((rho / 0.9999 + (double)c->grid.s0) / (double)c->grid.s0) * 1.01;
-  static const double kFactors[] = {2.5, 3.0, 4.0, 5.5, 8.0};
-  double factor = kFactors[4];  // (a camera farther out than that: its rays take the far path, as any camera beyond 2 s0 did)
-  for (double f : kFactors) if (f >= need) { factor = f; break; }
+  if (policy != 2 && !grid_in_use(c)) return PT_OK;  // (a forced list / hierarchy walk never reads the grid: no rebuild, no stream synchronisation)
+  if (policy == 2 && c->geom_policy != PT_GEOM_AUTO && c->geom_policy != PT_GEOM_GRID) return PT_OK;
+  const double factor = view_need_factor(c);
+  if (factor <= 0.0) return PT_OK;
 #ifdef PT_DEV_KNOBS
   if (getenv("PT_GRID_DNEAR")) return PT_OK;  // (the A/B build's own factor stands)
 #endif
   if (std::fabs(factor - (double)c->grid.near_factor) < 1e-6) return PT_OK;
+  if (policy == 1 && factor < (double)c->grid.near_factor) return PT_OK;
   ptgrid::Grid grid;
   const uint32_t n = (uint32_t)c->h_radii.size();
   if (!build_grid(c->h_geom.data(), c->h_radii.data(), n, factor, &grid)) return PT_OK;  // (no grid for that factor: the one in place stays)
   PT_HIP(c, hipSetDevice(c->device));
   PT_HIP(c, hipStreamSynchronize(c->stream));  // launches in flight read the grid in place
+  const int tuned = c->geom_tuned;
   int rc = install_grid(c, grid, c->h_mat.data(), n);
   c->epoch++;
   list_paths(c);  // (which kernels the grid can feed, and whether PT_GEOM_AUTO has anything to measure, follow its size — or its absence, had the upload failed)
+  if (policy != 2 && rc == PT_OK && tuned == PT_GEOM_GRID && c->have_grid) c->geom_tuned = tuned;  // a refit keeps the settled choice
   return rc;
 }
 
 } // namespace
 
+PT_API int pt_refit_grid(pt_ctx* c, int only_if_stale) {
+  if (!c) return PT_ERR_INVALID;
+  if (!c->have_spheres || !c->have_params) return PT_OK;
+  return fit_grid_to_view(c, only_if_stale ? 1 : 0);
+}
+
+PT_API int pt_grid_fit(pt_ctx* c) {
+  if (!c) return PT_ERR_INVALID;
+  return grid_fit_state(c);
+}
+
 PT_API int pt_tune(pt_ctx* c, uint32_t n_passes) {
   if (!c || n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_tune: bad argument");
   if (c->have_spheres) {
-    int rc = fit_grid_to_view(c);
+    int rc = fit_grid_to_view(c, 2);
     if (rc != PT_OK) return rc;
   }
   if (c->geom_policy != PT_GEOM_AUTO || !c->have_spheres || c->n_trials < 2) return PT_OK; // nothing to decide

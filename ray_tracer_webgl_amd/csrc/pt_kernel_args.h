@@ -131,7 +131,7 @@ enum { PT_COH_BINS = 66, PT_HIST_WAVE_STRIDE = 8 };  // cell_hist: bins 0..64 = 
 enum { PT_REG_REFILL_DECODE = 0, PT_REG_REFILL_RESERVE, PT_REG_CAMERA_RAY, PT_REG_SHADE_HIT_RECORD, PT_REG_SHADE_SKY, PT_REG_SHADE_DIFFUSE,
        PT_REG_SHADE_METAL, PT_REG_SHADE_GLASS, PT_REG_SHADE_GLASS_REFRACT, PT_REG_SHADE_CONTINUES, PT_REG_SHADE_FINISHED, PT_REG_SHADE_ITEM_STORE,
        PT_REG_WALK_ENTRY, PT_REG_WALK_ENTER_CELL, PT_REG_WALK_FAR_RAY, PT_REG_SHADE_ANY, PT_N_REGIONS };
-enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_SCRATCH = 7 /* host-side save / restore of a counter around a probe launch */, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128,
+enum { PT_CTR_HEAD = 0, PT_CTR_SEGMENTS = 1, PT_CTR_SAMPLES = 2, PT_CTR_FAR_RAYS = 3 /* grid walk: segments handed to the whole list because they reached the grid from outside its near region */, PT_CTR_SCRATCH = 7 /* host-side save / restore of a counter around a probe launch */, PT_CTR_WORK = 8, PT_CTR_LITERAL = 16, PT_CTR_PHASES = 24, PT_N_PHASES = 8, PT_CTR_REGIONS = 32, PT_CTR_TIMEBINS = 64, PT_CTR_COUNT = 128,
        PT_QUEUE_GROUPS_MAX = 256, PT_CTR_GROUP_HEADS = 128 /* then PT_QUEUE_GROUPS_MAX heads, 8 u64 (one 64-byte line) apart */,
        PT_CTR_ALLOC = PT_CTR_GROUP_HEADS + 8 * PT_QUEUE_GROUPS_MAX };  // [64..127]: COUNT twins, segments shaded per 0.655 ms bin of s_memrealtime
 

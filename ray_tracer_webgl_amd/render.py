@@ -20,8 +20,9 @@ def main(argv=None):
     ap.add_argument("--passes", type=int)
     ap.add_argument("--max-depth", type=int)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--geometry", default="auto", choices=["auto", "lds", "scalar", "bvh"],
-                    help="how the kernel looks at the sphere list (same image bits on every path)")
+    ap.add_argument("--geometry", default="auto", choices=["auto", "lds", "scalar", "bvh", "grid", "small"],
+                    help="how the kernel looks at the sphere list (same image bits on every path; auto: the library measures "
+                         "the usable ones — the grid walk on scenes of hundreds of spheres, the small-list kernels up to 16)")
     ap.add_argument("--out", default="render.png")
     ap.add_argument("--checkpoint", help="also save the fp32 accumulation buffer (.npz)")
     args = ap.parse_args(argv)
@@ -29,11 +30,7 @@ def main(argv=None):
     make = scenes.CONFIGS[args.config]
     sc = make()
     if args.width and args.height:
-        kw = {}
-        if args.config == "default":
-            sc = make(args.width, args.height)
-        else:
-            sc = make(args.width, args.height)
+        sc = make(args.width, args.height)
     p = sc.params
     if args.spp_per_pass:
         p.samples_per_pixel = args.spp_per_pass
@@ -42,8 +39,11 @@ def main(argv=None):
     if args.passes:
         sc.n_passes = args.passes
     t0 = time.perf_counter()
-    geom = {"auto": abi.PT_GEOM_AUTO, "lds": abi.PT_GEOM_LDS, "scalar": abi.PT_GEOM_SCALAR, "bvh": abi.PT_GEOM_BVH}[args.geometry]
-    pt, acc = render_scene(sc, device=args.device, passes_per_launch=min(sc.n_passes, 16), geometry_path=geom)
+    geom = {"auto": abi.PT_GEOM_AUTO, "lds": abi.PT_GEOM_LDS, "scalar": abi.PT_GEOM_SCALAR, "bvh": abi.PT_GEOM_BVH,
+            "grid": abi.PT_GEOM_GRID, "small": abi.PT_GEOM_SMALL}[args.geometry]
+    per = min(sc.n_passes, 16)
+    # (pt_tune first, as bench.py does: the grid fitted to this camera, PT_GEOM_AUTO settled before the frame's launches)
+    pt, acc = render_scene(sc, device=args.device, passes_per_launch=per, geometry_path=geom, tune=min(per, 8))
     dt = time.perf_counter() - t0
     st = pt.stats()
     frame = pt.resolve(gamma=True)

@@ -26,16 +26,8 @@ class PathTracer:
         self.width, self.height = int(width), int(height)
         self.device = int(device)
         self._ctx = C.c_void_p()
-        rc = self.lib.pt_create(C.byref(self._ctx), self.device, self.width, self.height)
-        if rc != abi.PT_OK:
-            msg = self.lib.pt_last_error(None)
-            self._ctx = C.c_void_p()
-            raise PtError(rc, msg.decode() if msg else "pt_create failed")
-        self.params = None
-        self.local_rows = self.height
         self.use_torch = bool(use_torch)
-        self.accum_tensor = None
-        self._keep = None
+        stream_handle = None
         if self.use_torch:
             import torch
 
@@ -43,13 +35,25 @@ class PathTracer:
             try:
                 stream = torch.cuda.current_stream(self.device)
             except RuntimeError as e:  # e.g. "No HIP GPUs are available": a second HIP runtime in this process (_lib.py)
-                self.close()
                 raise PtError(abi.PT_ERR_NO_DEVICE, "PyTorch cannot see the GPU libptrace is using (%s): two HIP runtimes in one "
                               "process?  `import torch` before anything of ray_tracer_webgl_amd" % e) from e
             # torch's default stream is the NULL stream, and NULL means "the context's own stream" in this
             # ABI: name it as hipStreamLegacy (1).  Kernels must run on the stream torch orders its own work
             # on, or a gather / .cpu() right after render_passes reads the buffer before they have written it.
-            self._check(self.lib.pt_set_stream(self._ctx, C.c_void_p(stream.cuda_stream or abi.PT_STREAM_LEGACY)))
+            # The context is CREATED on that stream (pt_create_on_stream): it never makes a stream — an HSA queue,
+            # 80-150 ms when it is the process's first — that it would not use.
+            stream_handle = C.c_void_p(stream.cuda_stream or abi.PT_STREAM_LEGACY)
+            rc = self.lib.pt_create_on_stream(C.byref(self._ctx), self.device, self.width, self.height, stream_handle)
+        else:
+            rc = self.lib.pt_create(C.byref(self._ctx), self.device, self.width, self.height)
+        if rc != abi.PT_OK:
+            msg = self.lib.pt_last_error(None)
+            self._ctx = C.c_void_p()
+            raise PtError(rc, msg.decode() if msg else "pt_create failed")
+        self.params = None
+        self.local_rows = self.height
+        self.accum_tensor = None
+        self._keep = None
 
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, rc):
@@ -134,6 +138,20 @@ class PathTracer:
         self._check(self.lib.pt_tune(self._ctx, int(n_passes)))
         if self.accum_tensor is not None:
             self.accum_tensor.zero_()
+
+    def refit_grid(self, only_if_stale=False):
+        """Rebuild the grid for the margin class the current camera needs (pt_refit_grid): what a frame loop does when
+        grid_fit() says 1.  No measuring launches; accumulation, textures and statistics stay."""
+        self._check(self.lib.pt_refit_grid(self._ctx, 1 if only_if_stale else 0))
+
+    def grid_fit(self):
+        """0: the grid fits the camera of the last set_params (or there is none / another path is in use); 1: the camera
+        stands outside the region whose rays walk the cells — every primary ray is tested against the whole list;
+        2: a smaller margin class would do.  Host arithmetic, no synchronisation (PtStats.grid_fit_stale)."""
+        rc = self.lib.pt_grid_fit(self._ctx)
+        if rc < 0:
+            raise PtError(rc, "pt_grid_fit failed")
+        return rc
 
     def reserve_passes(self, n):
         self._check(self.lib.pt_reserve_passes(self._ctx, int(n)))
@@ -250,8 +268,10 @@ class PathTracer:
         return out
 
 
-def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=None, geometry_path=None):
-    """Render a scenes.Scene completely; returns (PathTracer, accum ndarray)."""
+def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=None, geometry_path=None, tune=None):
+    """Render a scenes.Scene completely; returns (PathTracer, accum ndarray).  `tune` = n: pt_tune(n) after scene and
+    uniforms are up, as bench.py does before it times anything — the grid is refitted to the camera and PT_GEOM_AUTO
+    settled with n-pass launches (the as-benchmarked path: tests that pin what the bench line times pass it)."""
     p = scene.params.copy()
     if band is not None:
         p.band_rows, p.band_index, p.band_count = band
@@ -261,7 +281,9 @@ def render_scene(scene, device=0, use_torch=False, passes_per_launch=None, band=
     pt.set_spheres(scene.spheres)
     pt.set_params(p)
     per = passes_per_launch or scene.n_passes
-    pt.reserve_passes(per)
+    pt.reserve_passes(max(per, int(tune or 0)))
+    if tune:
+        pt.tune(int(tune))
     done = 0
     while done < scene.n_passes:
         k = min(per, scene.n_passes - done)

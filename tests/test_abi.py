@@ -205,7 +205,7 @@ def test_rust_binding_lists_the_render_abi():
     the header with the same argument count."""
     text = open(os.path.join(ROOT, "bindings", "rust", "ptrace_sys.rs")).read()
     header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
-    for name in ["pt_create", "pt_destroy", "pt_resize", "pt_set_spheres", "pt_set_params", "pt_render",
+    for name in ["pt_create", "pt_create_on_stream", "pt_grid_fit", "pt_refit_grid", "pt_destroy", "pt_resize", "pt_set_spheres", "pt_set_params", "pt_render",
                  "pt_render_passes", "pt_reserve_passes", "pt_reset_accum", "pt_synchronize", "pt_resolve",
                  "pt_resolve_rgba8", "pt_blend_rgba8", "pt_accum_ptr", "pt_bind_accum", "pt_read_accum", "pt_load_accum",
                  "pt_set_stream", "pt_set_option", "pt_tune", "pt_clear_textures", "pt_render_frame", "pt_render_frames",

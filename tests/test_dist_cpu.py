@@ -228,3 +228,44 @@ def test_frame_loop_cpu_baseline_replays_the_reference_ticks():
             os.environ["PT_ORACLE_LIB"] = keep
     assert c["unit"] == "frames/s" and c["value"] > 0 and c["mray_s"] > 0 and c["cores"] >= 1 and c["kind"] == "port"
     assert c["sample"].split()[0].isdigit() and int(c["sample"].split()[0]) >= 2
+
+
+def test_a_counter_record_of_another_build_is_refused():
+    """VERDICT r5 #4.  bench.py attaches the committed rocprofv3 counter record of the timed kernel (profiles/pmc_traffic.json)
+    to its line, labelled PRIOR.  A record is only as good as the build it was collected on: profiles/summarize.py stamps it
+    with the sha256 of the kernel sources the profiled bench line reported (_lib.build_identity), and a record of another
+    build — or of none, like the records of rounds 1-5 — is refused: `stale` true, no figures, no traffic; the ratio of the
+    record's kernel time to this run's is printed either way.  A record of THIS build yields the figures, with the fp32
+    fraction counting FMA, MUL and ADD (the figure the committed summaries are recomputed to).  CPU only."""
+    import importlib.util
+
+    from ray_tracer_webgl_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ident = _lib.build_identity()
+    assert len(ident["csrc_sha256"]) == 64 and ident == _lib.build_identity() and ident["abi"] == 5
+    rec = {"kernel": "pt_trace_kernel_grid", "config": "2", "kernel_ms": 111.5, "valu_issue_frac": 0.786,
+           "sq_thread_cycles_valu": 4.32191e12, "sq_active_inst_valu": 1.07898e11, "sq_insts_valu_fma_f32": 2.33195e10,
+           "sq_insts_valu_mul_f32": 1.18834e10, "sq_insts_valu_add_f32": 1.16189e10, "sq_insts_salu": 2.74e10,
+           "valu_insts_per_launch": 1.06215e11, "sq_lds_bank_conflict": 1.3e9, "sq_lds_idx_active": 1.32e10,
+           "hbm_bytes_per_pass": 35579005, "profile": "profiles/x_summary.txt"}
+    for foreign in (dict(rec), dict(rec, csrc_sha256="0" * 64)):
+        c = bench.counters_of(foreign, 109.5, ident)
+        assert c["stale"] is True and "valu_issue_frac" not in c and "fp32_flop_frac" not in c
+        assert c["prior_over_this_run_kernel_ms"] == round(111.5 / 109.5, 4) and c["this_build_csrc_sha256"] == ident["csrc_sha256"]
+        assert bench.fresh(foreign, ident) is None
+    own = dict(rec, csrc_sha256=ident["csrc_sha256"])
+    c = bench.counters_of(own, 109.5, ident)
+    assert c["stale"] is False and c["valu_issue_frac"] == 0.786 and bench.fresh(own, ident) is own
+    assert abs(c["lane_utilisation"] - 0.6259) < 1e-3
+    assert abs(c["fp32_flop_frac"] - 0.160) < 2e-3  # (2 FMA + MUL + ADD): VERDICT r5's recomputation of the round-5 record
+    assert bench.counters_of(None, 1.0, ident) is None
+    # every record committed under profiles/ names the build it belongs to, or is refused by the line
+    import json
+
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for r in doc["records"]:
+        c = bench.counters_of(r, r.get("kernel_ms"), ident)
+        assert c["stale"] == (r.get("csrc_sha256") != ident["csrc_sha256"])

@@ -171,6 +171,88 @@ def test_translated_scenes_through_the_grid(ora, seed, offset):
     t.close()
 
 
+def test_a_fixed_slice_of_the_long_fuzz(ora):
+    """VERDICT r5 #1d: what tools/long_fuzz.py runs by the ten thousand, 150 scenes of it in the suite, fixed seeds, one test
+    (one context after the other, one process).  30 lists of 1 ... 15 spheres through the small-list kernels (every length
+    modulo four: one build each); 120 scenes through the grid walk, every second one on a grid pt_tune has REFITTED to a
+    camera placed for one of the seven margin classes in turn (2.5 ... 16 s0: another d_near, other per-sphere margins,
+    another set of entries) — where the host-side fit flag must say what is the case before (too small / looser than
+    needed / fits) and after (fits).  Bits and segments against the oracle, scene by scene."""
+    import ctypes as C
+
+    from ray_tracer_webgl_amd.tracer import PathTracer
+    from test_grid import build as grid_build
+
+    classes = [2.5, 3.0, 4.0, 5.5, 8.0, 12.0, 16.0]
+    bad, hit, small_builds, refit_scenes, through_grid = [], set(), set(), 0, 0
+    for i in range(150):
+        seed = 77000 + i
+        rng = np.random.default_rng(seed)
+        if i % 5 == 0:  # the small-list kernels
+            n = 1 + (i // 5) % 15
+            sc = random_scene(rng, n, int(rng.integers(9, 150)), int(rng.integers(5, 90)), int(rng.integers(1, 9)),
+                              int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 4)))
+            t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, sc.n_passes + 1)), geometry_path=abi.PT_GEOM_SMALL)
+            assert t.stats().geometry_path == abi.PT_GEOM_SMALL
+            small_builds.add(n % 4)
+        else:
+            n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500]))
+            width, height = int(rng.integers(9, 150)), int(rng.integers(5, 90))
+            if n >= 400:
+                width, height = min(width, 64), min(height, 40)
+            sc = random_scene(rng, n, width, height, int(rng.integers(1, 9)), int(rng.choice([1, 3, 8, 50])), int(rng.integers(1, 4)))
+            refit = i % 2 == 1
+            if refit or seed % 3 != 1:  # mostly small spheres, spread out: what a grid is for
+                small = rng.random(n) < 0.9
+                sc.spheres["radius"][small] = (np.sign(sc.spheres["radius"][small]) * rng.uniform(0.05, 0.4, small.sum())).astype(np.float32)
+                sc.spheres["center"] *= np.float32(rng.choice([2.0, 6.0, 20.0]))
+            if seed % 4 == 0:  # a flat field: one layer of cells
+                sc.spheres["center"][:, 1] = np.float32(0.3)
+            rc, g = grid_build(sc.spheres)
+            if refit and rc == 0:
+                # the camera where margin class `want` is the smallest that covers it, looking at the scene's middle
+                want = classes[(i // 2) % len(classes)]
+                c0, s0 = g["c0"].astype(np.float64), float(g["s0"])
+                d = rng.normal(size=3)
+                d /= np.linalg.norm(d)
+                la = abi.PtLookAtIn()
+                la.width, la.height = width, height
+                la.look_from = abi.d3(*(c0 + d * (want / 1.01 - 1.0) * 0.97 * s0))
+                la.look_at = abi.d3(*(c0 + rng.uniform(-0.2, 0.2, 3) * s0))
+                la.vup = abi.d3(0, 1, 0)
+                la.vfov_radians = math.radians(rng.uniform(15, 60))
+                la.focus_distance = max(want - 1.0, 0.5) * s0
+                la.aperture = 0.0
+                assert scenes._lib().pt_camera_look_at(C.byref(la), C.byref(sc.params)) == 0
+                t = PathTracer(width, height)
+                t.set_geometry_path(abi.PT_GEOM_GRID)
+                t.set_spheres(sc.spheres)
+                t.set_params(sc.params)
+                t.reserve_passes(sc.n_passes)
+                need = float(t.stats().grid_need_factor)  # (normally `want`; the library's own c0 / s0 decide)
+                assert need in classes and t.grid_fit() == (1 if need > 3.0 else (2 if need < 3.0 else 0)), (seed, want, need, t.grid_fit())
+                t.tune(1)
+                st = t.stats()
+                if abs(st.grid_near_factor - need) < 1e-6:  # (a scene that gets no grid for that class keeps the one in place)
+                    assert st.grid_fit_stale == 0 and t.grid_fit() == 0, (seed, need, st.grid_fit_stale)
+                    hit.add(need)
+                    refit_scenes += 1
+                t.set_params(sc.params)
+                t.render_passes(sc.n_passes)
+                got = t.accum()
+            else:
+                t, got = render_scene(sc, passes_per_launch=int(rng.integers(1, sc.n_passes + 1)), geometry_path=abi.PT_GEOM_GRID)
+            through_grid += int(t.stats().geometry_path == abi.PT_GEOM_GRID)
+        ref, seg = ora.render(sc.spheres, sc.params, sc.n_passes)
+        if not (np.array_equal(bits(got), bits(ref)) and t.stats().segments == seg):
+            bad.append((seed, len(sc.spheres), int((bits(got) != bits(ref)).sum()), t.stats().geometry_path))
+        t.close()
+    assert not bad, bad
+    assert small_builds == {0, 1, 2, 3}
+    assert hit == set(classes), sorted(hit)  # every margin class was walked at least once
+    assert refit_scenes >= 50 and through_grid >= 100, (refit_scenes, through_grid)
+
+
 def test_the_grid_fuzz_did_run_through_the_grid():
     assert len(GRID_USED) == 48 and sum(GRID_USED) >= 36, GRID_USED
 

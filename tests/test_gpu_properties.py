@@ -170,6 +170,78 @@ def test_config2_full_resolution_whole_frame_vs_oracle(ora):
     t.close()
 
 
+def _whole_frame_vs_oracle(ora, t, sc, what):
+    """One launch of sc.n_passes passes on the context `t` AS IT STANDS (its grid, its settled path) against the oracle,
+    every pixel and the segment count."""
+    t.reset()
+    t.set_params(sc.params)
+    t.render_passes(sc.n_passes)
+    a = t.accum()
+    ref, seg = ora.render(sc.spheres, sc.params, sc.n_passes)
+    g, r = bits(a), bits(ref)
+    assert np.array_equal(g, r), "%s: %d of %d values differ from the oracle" % (what, (g != r).sum(), g.size)
+    assert t.stats().segments == seg, (what, t.stats().segments, seg)
+    return a
+
+
+def test_config5_as_benchmarked_whole_frame_vs_list_walk_and_oracle(ora):
+    """VERDICT r5 #1a.  `bench.py --config 5` times the grid AFTER pt_tune has refitted it to the camera (margin class
+    2.5 s0 instead of the 3 s0 pt_set_spheres builds for, each sphere registered with its own margin: fewer entries) —
+    not the grid the other full-size tests walk.  Here the as-benchmarked context (same scene call, same pass shape,
+    same decorrelated pass times, pt_tune(8) like bench.py) renders the WHOLE 1920x1080 frame: one 16-spp pass against
+    the reference's own algorithm on the device (the scalar list walk: every sphere for every ray), bits and segments,
+    and one 1-spp pass against the ORACLE (2x10^6 pixels x 10 001 spheres: ~half a minute of the box's cores)."""
+    sc = scenes.config5(1920, 1080, 16, 1, 50)
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    built = PathTracer(1920, 1080)
+    built.set_spheres(sc.spheres)
+    n_built = built.stats().grid_entries
+    built.close()
+    t, a = render_scene(sc, tune=8)  # bench.py: pt.tune(min(passes per launch, 8))
+    st = t.stats()
+    assert st.geometry_path == abi.PT_GEOM_GRID and st.geometry_tuned == 1
+    # the REFIT grid, not the one pt_set_spheres built
+    assert abs(st.grid_near_factor - 2.5) < 1e-6 and st.grid_fit_stale == 0, (st.grid_near_factor, st.grid_fit_stale)
+    assert 0 < st.grid_entries < n_built, (st.grid_entries, n_built)
+    assert st.far_rays < 1e-4 * st.segments, (st.far_rays, st.segments)
+    t2, b = render_scene(sc, geometry_path=abi.PT_GEOM_SCALAR)
+    assert t2.stats().geometry_path == abi.PT_GEOM_SCALAR
+    g, r = bits(a), bits(b)
+    assert np.array_equal(g, r), "refit grid vs list walk: %d of %d values differ" % ((g != r).sum(), g.size)
+    assert t2.stats().segments == st.segments
+    t2.close()
+    one = scenes.config5(1920, 1080, 1, 1, 50)
+    one.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    _whole_frame_vs_oracle(ora, t, one, "config 5 on the refit grid, 1 spp")
+    assert t.stats().grid_entries == st.grid_entries and t.stats().geometry_path == abi.PT_GEOM_GRID
+    t.close()
+
+
+def test_config3_4k_as_benchmarked_whole_frame_vs_oracle(ora):
+    """VERDICT r5 #1b.  The cover scene at 3840x2160 through the context bench.py --config 3 sets up (pt_tune: the grid
+    refitted to the camera at (13, 2, 3), PT_GEOM_AUTO settled): every one of the 8.3x10^6 pixels against the oracle,
+    one pass of 2 spp at depth 50."""
+    sc = scenes.config3(3840, 2160, 2, 1, 50)
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    t, _ = render_scene(sc, tune=8)
+    assert t.stats().geometry_path == abi.PT_GEOM_GRID and t.stats().grid_fit_stale == 0
+    _whole_frame_vs_oracle(ora, t, sc, "config 3 at 4K, 2 spp")
+    t.close()
+
+
+def test_config4_as_benchmarked_whole_frame_vs_oracle(ora):
+    """VERDICT r5 #1c.  The closed room at 1024x1024 through the small-list kernel PT_GEOM_AUTO settles on after pt_tune
+    (nine spheres: no grid to fit): every pixel against the oracle, one pass of 8 spp at depth 50 (mean path ~40 segments)."""
+    sc = scenes.config4(1024, 1024, 8, 1, 50)
+    sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    t, _ = render_scene(sc, tune=8)
+    # (whichever list kernel PT_GEOM_AUTO measured fastest on this box — at this size the small-list kernel, bench.py's
+    # pt_trace_kernel_small_t1; the other two candidates walk the same nine spheres)
+    assert t.stats().geometry_path in (abi.PT_GEOM_SMALL, abi.PT_GEOM_LDS, abi.PT_GEOM_SCALAR) and t.stats().grid_near_factor == 0.0
+    _whole_frame_vs_oracle(ora, t, sc, "config 4, 8 spp")
+    t.close()
+
+
 def _bench(*extra, timeout=900):
     import subprocess
     import sys
@@ -224,7 +296,10 @@ def test_bench_under_the_drivers_flags_still_carries_its_verdicts():
     d = _bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-list-walk", "--no-first-frame")
     assert d["n_gpus"] == 1 and d["gather_matches_single_gpu"] is True, d["gather_check"]
     assert d["roofline"]["executed"]["twin_segments_equal_timed_kernel"] is True
-    assert d["roofline"]["counters"] is None or d["roofline"]["counters"]["valu_issue_frac"] > 0
+    c = d["roofline"]["counters"]  # the committed PMC record of this kernel: attached when it was collected on THIS build, refused otherwise
+    assert c is None or (c["stale"] is True and "valu_issue_frac" not in c) or (c["stale"] is False and c["valu_issue_frac"] > 0)
+    assert c is None or c["prior_over_this_run_kernel_ms"] > 0
+    assert d["build"]["csrc_sha256"] and (c is None or c["this_build_csrc_sha256"] == d["build"]["csrc_sha256"])
 
 
 def test_bench_rccl_path_with_one_rank():
