@@ -284,6 +284,28 @@ def setup_times(pt):
     return {"library_ms": {names[k]: round(buf[k], 3) for k in range(max(n, 0))}}
 
 
+# A timed region of N ranks is 1/N as long as the single-GPU one (config 2 at N = 8: 20 ms), and so is everything before
+# it: a device that comes out of idle has not reached its clocks by then, and the rank that starts coldest sets the job's time
+# (one-device rehearsal, profiles/r06_band_rehearsal.txt: the first of eight ranks 19.9 ms, the same rank on a warm device
+# 18.4).  After the W warm-up steps the launches of those steps are therefore repeated — untimed, same launch shape — until
+# the device has been busy this long, for every N alike (N = 1 reaches it with two repeats of its own warm-up).
+CLOCK_WARMUP_MS = 200.0
+
+
+def keep_busy(pt, run, steps, busy_ms, limit=256):
+    """run(steps) again and again (untimed) until the context's kernel time since its last reset reaches busy_ms; returns it"""
+    import torch
+
+    n = 0
+    while True:
+        torch.cuda.synchronize()
+        done = float(pt.stats().render_kernel_ms)
+        if done >= busy_ms or n >= limit:
+            return done
+        run(max(int(steps), 1))
+        n += 1
+
+
 def plan_steps(converged_spp, spp_per_pass, passes_per_step, steps):
     """(steps, spp per step): the default step count is the config's converged frame."""
     spp_step = spp_per_pass * passes_per_step
@@ -313,6 +335,9 @@ def main():
                     help="N > 1: rows per interleaved band (4: rank shares of the work within 1 %% of each other at N = 8)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the same frame for every N (BASELINE's workload); weak = passes per step grow with N")
+    ap.add_argument("--clock-warmup-ms", type=float, default=CLOCK_WARMUP_MS,
+                    help="after the --warmup steps, repeat them (untimed) until the device has been busy this long: the clocks of a device "
+                         "that was idle a moment ago (0 = only the --warmup steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-list-walk", action="store_true",
                     help="skip the extra (untimed-region) launch that measures the reference's linear list walk")
@@ -472,6 +497,7 @@ def main():
 
     # warmup (untimed), then clear accumulation and statistics
     run_steps(args.warmup, 1000.0)
+    clock_warmup_ms = keep_busy(pt, lambda k: run_steps(k, 1000.0), args.warmup, args.clock_warmup_ms) if args.clock_warmup_ms > 0 else None
     if use_dist:
         gather(pt.accum_tensor)  # also sets up the RCCL channels outside the timed region
     sync_all()
@@ -755,6 +781,7 @@ def main():
             "ranks": ranks_seen,
             "steps": steps,
             "warmup": args.warmup,
+            "untimed_busy_ms_before_the_timed_region": round(clock_warmup_ms, 1) if clock_warmup_ms is not None else None,
             "ms_per_step": round(wall / steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak" if weak else "strong",

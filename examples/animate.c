@@ -52,6 +52,9 @@ int main(int argc, char** argv) {
   p.time_step = (float)interval;                      /* tick k renders at u_time = now0 + k * interval */
   p.first_pass = 0;
   CHECK(pt_set_params(ctx, &p));
+  /* the camera may have moved since the grid of a large scene was fitted (State::update_position, src/state.rs:411-441):
+   * host arithmetic, 0 for State::default's nine spheres (no grid) — INTEGRATION.md §1 */
+  if (pt_grid_fit(ctx) == 1) CHECK(pt_refit_grid(ctx, 0));
   CHECK(pt_render_frames(ctx, v.even_odd_count, v.max_render_count, n));  /* webgl::render, n times */
   for (uint32_t k = 1; k < n; k++) pt_state_update_render_globals(st);    /* the host's counters follow */
 

@@ -96,6 +96,8 @@ enum {
                              never ends a path early — so images of this mode match the oracle only
                              statistically; it exists for deep-bounce scenes (BASELINE config 4: mean path
                              length 40 segments).  0 = off (default): bit-exact against the oracle. */
+  PT_OPT_GRID_FIT = 6,    /* how pt_tune chooses the grid's margin class.  0 (default): it measures the candidates (see
+                             pt_tune).  1: the smallest class that covers the camera, no launches.  Speed only. */
 };
 
 /* ---- background modes ----------------------------------------------------------------------- */
@@ -213,8 +215,8 @@ typedef struct PtStats {
   uint32_t grid_fit_stale;  /* does the grid still fit the camera of the last pt_set_params?  0: yes (or no grid / not the
                                path in use).  1: NO — the camera stands outside the region whose rays walk the cells, so every
                                primary ray takes the far path (exact, but tested against the WHOLE list): call pt_refit_grid
-                               (or pt_tune).  2: looser than needed — a smaller margin class would cover the camera (a few
-                               per cent of speed, never a cliff).  The reference moves its camera every tick
+                               (or pt_tune).  2: looser than needed — a smaller margin class (not below the default, 3) would
+                               cover the camera (a few per cent of speed, never a cliff).  The reference moves its camera every tick
                                (src/state.rs:411-441); pt_set_params only sets this flag, it never rebuilds.       */
   /* executed work of the walk kernels since the last reset, filled when PT_OPT_COUNT_WORK is on:
    * [0] walk iterations (node steps / cell steps, wave-level)   [1] lanes active in them (sum)
@@ -223,7 +225,7 @@ typedef struct PtStats {
    * [6] wave steps                                              [7] lanes carried over (sum)   */
   uint64_t work[8];
   float grid_near_factor;   /* d_near / s0 the grid in place was built for (3 from pt_set_spheres; pt_tune / pt_refit_grid
-                               choose among 2.5 / 3 / 4 / 5.5 / 8); 0 = no grid                                        */
+                               choose among 2.5 / 3 / 4 / 5.5 / 8 / 12 / 16); 0 = no grid                              */
   float grid_need_factor;   /* the smallest of those classes that covers the current camera and its lens           */
   uint64_t far_rays;        /* ray segments since the last reset that reached the grid from OUTSIDE its near region and
                                were therefore tested against the whole list (grid walk only; ~0 on a fitted grid)     */
@@ -334,24 +336,29 @@ int pt_write_texture(pt_ctx* ctx, int index, const uint8_t* rgba_in);
 /* ---- diagnostics ------------------------------------------------------------------------------ */
 int pt_get_stats(pt_ctx* ctx, PtStats* out);
 int pt_set_option(pt_ctx* ctx, int key, int value);
-/* Fits the context to scene AND uniforms.  (i) The uniform grid pt_set_spheres built for rays that start within twice
- * the scene's radius of its middle is rebuilt for the smallest margin class that covers the camera set by pt_set_params
- * (closer cameras: fewer copies per sphere; a camera far out: a grid that serves its rays at all) — speed only, the image
- * does not depend on it; skipped once a launch has been captured into a caller's hipGraph.  (ii) Settles PT_GEOM_AUTO now
+/* Fits the context to scene AND uniforms.  (i) The uniform grid pt_set_spheres built for rays that start within twice the
+ * scene's radius of its middle is rebuilt for the margin class that renders THIS view fastest: the smallest class that
+ * covers the camera set by pt_set_params is a lower bound (a camera outside it sends every primary ray down the far path), and
+ * whether a class at or above it wins depends on where bounce rays start, so the candidates are measured — one timed launch of
+ * n_passes passes each: the class the camera needs, the default class when that is smaller, and up to two classes wider while
+ * the launch's far-ray tally says such rays matter and the wider class keeps winning (pt_set_option PT_OPT_GRID_FIT 1: no
+ * launches, the class the camera needs).  Speed only, the image does not depend on it; skipped once a launch has been captured
+ * into a caller's hipGraph.  (ii) Settles PT_GEOM_AUTO now
  * instead of lazily: renders n_passes passes with the current scene
- * and uniforms once cold and once per usable path, keeps the fastest path, then clears the
- * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes.
+ * and uniforms once cold and once per usable path, keeps the fastest path.  Whenever it has launched anything it clears the
+ * accumulation and statistics again.  Synchronous; a set-up call like pt_reserve_passes (which must have reserved n_passes).
  * Call it before capturing pt_render* into a hipGraph: a captured launch keeps the path it was
  * captured with (no measuring happens while a stream is capturing). */
 int pt_tune(pt_ctx* ctx, uint32_t n_passes);
-/* Part (i) of pt_tune alone: rebuild the grid for the margin class the CURRENT camera needs (PtStats.grid_need_factor) when
- * it differs from the one in place; nothing else — no measuring launches, accumulation, textures and statistics untouched.
- * What a frame loop calls when PtStats.grid_fit_stale (or pt_grid_fit(ctx)) says so: the reference's camera moves every tick
- * (State::update_position, src/state.rs:411-441), and a camera that has left the region the grid was fitted to sends every
- * primary ray down the far path.  Synchronises the stream when it rebuilds (~2 ms of host work for 10 000 spheres); a no-op
- * (PT_OK) when the grid fits, when there is none, when another geometry path is forced, and once a launch has been
- * captured into a caller's hipGraph (its arguments hold the old grid's numbers; pt_render_frames' own graphs are
- * re-captured by themselves).  `only_if_stale` != 0: rebuild only for state 1 (too small), keep a looser grid. */
+/* The frame loop's half of (i): rebuild the grid when the CURRENT camera has left the region it serves — for the smallest
+ * margin class that covers the camera, never below the default class (3 scene radii: whether a tighter class pays is a
+ * measurement, pt_tune's) — or, with only_if_stale == 0, also when the grid is looser than that.  Nothing else: no launches,
+ * accumulation, textures and statistics untouched.  What a frame loop calls when PtStats.grid_fit_stale (or pt_grid_fit(ctx))
+ * says so: the reference's camera moves every tick (State::update_position, src/state.rs:411-441), and a camera that has left
+ * the region the grid was fitted to sends every primary ray down the far path.  Synchronises the stream when it rebuilds
+ * (~2 ms of host work for 10 000 spheres); a no-op (PT_OK) when the grid fits, when there is none, when another geometry path
+ * is forced or settled, and once a launch has been captured into a caller's hipGraph (its arguments hold the old grid's
+ * numbers; pt_render_frames' own graphs are re-captured by themselves). */
 int pt_refit_grid(pt_ctx* ctx, int only_if_stale);
 /* PtStats.grid_fit_stale without the synchronisation pt_get_stats implies: 0 / 1 / 2 as there, < 0 on error.  Host arithmetic only. */
 int pt_grid_fit(pt_ctx* ctx);

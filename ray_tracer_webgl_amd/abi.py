@@ -29,7 +29,7 @@ PT_BG_SKY = 0
 PT_BG_BLACK = 1
 
 PT_GEOM_AUTO, PT_GEOM_LDS, PT_GEOM_SCALAR, PT_GEOM_BVH, PT_GEOM_GRID, PT_GEOM_SMALL = 0, 1, 2, 3, 4, 5
-PT_OPT_GEOMETRY_PATH, PT_OPT_COUNT_WORK, PT_OPT_CARRY_LANES, PT_OPT_REFILL_MIN, PT_OPT_RUSSIAN_ROULETTE = 1, 2, 3, 4, 5
+PT_OPT_GEOMETRY_PATH, PT_OPT_COUNT_WORK, PT_OPT_CARRY_LANES, PT_OPT_REFILL_MIN, PT_OPT_RUSSIAN_ROULETTE, PT_OPT_GRID_FIT = 1, 2, 3, 4, 5, 6
 PT_TIME_STEP_DECORRELATED = 0.3618034  # include/ptrace.h
 PT_STREAM_LEGACY = 1  # include/ptrace.h: hipStreamLegacy, the default (NULL) stream by name
 GEOM_NAMES = {0: "auto", 1: "lds", 2: "scalar", 3: "bvh", 4: "grid", 5: "small"}

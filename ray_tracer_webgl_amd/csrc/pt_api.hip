@@ -94,6 +94,7 @@ struct pt_ctx {
   PtMatRec* d_grid_mat = nullptr;
   size_t grid_cell_cap = 0, grid_entry_cap = 0;
   ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
+  int grid_fit_mode = 0;  // PT_OPT_GRID_FIT: 0 pt_tune measures the margin classes, 1 it takes the one the camera needs unmeasured
   int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
   uint32_t* d_cell_hist = nullptr;           // grid twins: leaf-round lanes per entry run + coherence bins (pt_debug_cell_hist)
   size_t cell_hist_cap = 0, cell_hist_n = 0;
@@ -951,7 +952,8 @@ static int fill_uniforms(pt_ctx* c, uint32_t n_passes, PtKernelArgs& A) {
   A.carry_lanes = c->carry_lanes;
   A.refill_min = c->refill_min;
 #ifdef PT_DEV_KNOBS // A/B builds only (tools/sweep_knobs.py); libptrace.so as shipped reads no environment variable (the Python
-                    // harness has ONE, PT_LIB: which build of this library ray_tracer_webgl_amd/_lib.py loads — a loader matter)
+                    // harness has two, both loader matters of ray_tracer_webgl_amd/_lib.py: PT_LIB — which build of this library it
+                    // loads — and PT_NO_TORCH_HIP_PRELOAD — do not map PyTorch's copy of the HIP runtime before it)
   if (const char* e = getenv("PT_CARRY_LANES")) A.carry_lanes = (uint32_t)atoi(e);
 #endif
   // cost feedback for the next launch's tile order: one atomicMax per item of pass 0.  A launch of one
@@ -1876,6 +1878,11 @@ PT_API int pt_set_option(pt_ctx* c, int key, int value) {
     c->carry_lanes = (uint32_t)value;
     return PT_OK;
   }
+  if (key == PT_OPT_GRID_FIT) { // how pt_tune chooses the grid's margin class; speed only, never results
+    if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: grid fit mode %d", value);
+    c->grid_fit_mode = value;
+    return PT_OK;
+  }
   return fail(c, PT_ERR_INVALID, "pt_set_option: unknown key %d", key);
 }
 
@@ -1884,19 +1891,21 @@ namespace {
 // FIT THE GRID TO THE VIEW.  pt_set_spheres builds the grid for rays that start within 2 s0 of the scene's middle (d_near =
 // 3 s0): it does not know where the camera will stand.  The margin every sphere is registered with grows with d_near^2 (the
 // cancellation in the shader's own `c` term: pt_grid.hpp), so a scene whose rays all start close by pays for rays that never
-// come — config 5, camera at 1.2 s0: 2.5 s0 instead of 3 is +2.8 % (profiles/r05_ab_runs.txt) — and a camera beyond 2 s0 turns
-// every primary ray into a far ray (exact, but tested against the whole list).  pt_tune — the synchronous set-up call that fits
-// the context to scene AND uniforms — and pt_refit_grid — what a frame loop calls when the camera has moved — rebuild the grid
-// for the smallest of a few factors that covers the camera (and its lens); bounce rays start on spheres, within s0, or on an
-// always-tested giant anywhere: those from beyond take the far path as before.  A matter of speed only: the image bits do not
-// depend on d_near.  Not after a launch has been captured into a caller's hipGraph (its arguments hold the old grid's numbers).
-// Whether the grid in place still fits is host arithmetic on the uniforms (grid_fit_state: PtStats.grid_fit_stale,
-// pt_grid_fit): pt_set_params never rebuilds — a rebuild synchronises the stream and moves device buffers.
+// come, and a camera beyond 2 s0 turns every primary ray into a far ray (exact, but tested against the whole list).  Two
+// entry points rebuild the grid for another of the classes kNearFactors: pt_tune — the synchronous set-up call that fits the
+// context to scene AND uniforms, and may launch: it MEASURES the candidates (tune_grid_to_view) — and pt_refit_grid — what a
+// frame loop calls when its camera has moved: host arithmetic only, the class the camera needs but never below the default.
+// A matter of speed only: the image bits do not depend on d_near.  Not after a launch has been captured into a caller's
+// hipGraph (its arguments hold the old grid's numbers).  Whether the grid in place still fits is host arithmetic on the
+// uniforms (grid_fit_state: PtStats.grid_fit_stale, pt_grid_fit): pt_set_params never rebuilds — a rebuild synchronises the
+// stream and moves device buffers.
 bool grid_in_use(const pt_ctx* c) {  // can the grid be what the next launch walks?
   if (!c->have_grid) return false;
   if (c->geom_policy == PT_GEOM_GRID) return true;
   return c->geom_policy == PT_GEOM_AUTO && (c->geom_tuned == 0 || c->geom_tuned == PT_GEOM_GRID);
 }
+
+constexpr double kDefaultNearFactor = 3.0;  // what pt_set_spheres builds for: rays that start within 2 s0 of the scene's middle
 
 int grid_fit_state(const pt_ctx* c) {
   if (!grid_in_use(c) || !c->have_params) return 0;
@@ -1904,22 +1913,14 @@ int grid_fit_state(const pt_ctx* c) {
   if (need <= 0.0) return 0;
   const double have = (double)c->grid.near_factor;
   if (have < need - 1e-6) return 1;  // the camera stands outside the near region: every primary ray takes the far path
-  return have > need + 1e-6 ? 2 : 0;
+  // looser than needed — measured against the default class, not against a class BELOW it: whether 2.5 s0 beats 3 s0 depends on
+  // where BOUNCE rays start (a camera that sees the ground out to the horizon sends them back from beyond any near region),
+  // which only a measurement knows (pt_tune); a refit never goes below the default
+  return have > std::max(need, kDefaultNearFactor) + 1e-6 ? 2 : 0;
 }
 
-// policy: 0 = rebuild whenever another class fits better, 1 = only when the class in place is too SMALL, 2 = pt_tune (like 0,
-// and whatever path PT_GEOM_AUTO had settled on: the measurement that follows decides anew)
-int fit_grid_to_view(pt_ctx* c, int policy) {
-  if (!c->have_grid || !c->have_params || c->captured || c->h_geom.empty()) return PT_OK;
-  if (policy != 2 && !grid_in_use(c)) return PT_OK;  // (a forced list / hierarchy walk never reads the grid: no rebuild, no stream synchronisation)
-  if (policy == 2 && c->geom_policy != PT_GEOM_AUTO && c->geom_policy != PT_GEOM_GRID) return PT_OK;
-  const double factor = view_need_factor(c);
-  if (factor <= 0.0) return PT_OK;
-#ifdef PT_DEV_KNOBS
-  if (getenv("PT_GRID_DNEAR")) return PT_OK;  // (the A/B build's own factor stands)
-#endif
-  if (std::fabs(factor - (double)c->grid.near_factor) < 1e-6) return PT_OK;
-  if (policy == 1 && factor < (double)c->grid.near_factor) return PT_OK;
+// replace the grid in place by one built for d_near = factor * s0 (the caller has decided that it should be)
+int rebuild_grid(pt_ctx* c, double factor, bool keep_tuned) {
   ptgrid::Grid grid;
   const uint32_t n = (uint32_t)c->h_radii.size();
   if (!build_grid(c->h_geom.data(), c->h_radii.data(), n, factor, &grid)) return PT_OK;  // (no grid for that factor: the one in place stays)
@@ -1929,8 +1930,101 @@ int fit_grid_to_view(pt_ctx* c, int policy) {
   int rc = install_grid(c, grid, c->h_mat.data(), n);
   c->epoch++;
   list_paths(c);  // (which kernels the grid can feed, and whether PT_GEOM_AUTO has anything to measure, follow its size — or its absence, had the upload failed)
-  if (policy != 2 && rc == PT_OK && tuned == PT_GEOM_GRID && c->have_grid) c->geom_tuned = tuned;  // a refit keeps the settled choice
+  if (keep_tuned && rc == PT_OK && tuned == PT_GEOM_GRID && c->have_grid) c->geom_tuned = tuned;  // a refit keeps the settled choice
   return rc;
+}
+
+// policy: 0 = rebuild whenever another class fits better, 1 = only when the class in place is too SMALL (pt_refit_grid: never below
+// the default class either way)
+int fit_grid_to_view(pt_ctx* c, int policy) {
+  if (!c->have_grid || !c->have_params || c->captured || c->h_geom.empty()) return PT_OK;
+  if (!grid_in_use(c)) return PT_OK;  // (a forced list / hierarchy walk never reads the grid: no rebuild, no stream synchronisation)
+  const int state = grid_fit_state(c);
+  if (state == 0 || (policy == 1 && state != 1)) return PT_OK;
+#ifdef PT_DEV_KNOBS
+  if (getenv("PT_GRID_DNEAR")) return PT_OK;  // (the A/B build's own factor stands)
+#endif
+  return rebuild_grid(c, std::max(view_need_factor(c), kDefaultNearFactor), true);
+}
+
+// pt_tune's part (i).  The smallest class that covers the CAMERA is a lower bound, not the answer: bounce rays start wherever the
+// camera's rays end, and those that start on an always-tested giant (the ground under a field) beyond the near region and come
+// back into the grid's box take the far path — one of them costs what hundreds of walked segments cost (the literal loop over
+// the list for one lane, or the whole wave 64 spheres at a time).  Measured on a 1 500-sphere field, camera inside it looking
+// across: the grid for 2.5 s0 renders the frame in 1.8 ms, the one for 3 s0 in 0.9 (profiles/r06_ab_runs.txt); on config 5
+// (camera above the field looking down) 2.5 s0 is 3 % faster.  So pt_tune MEASURES (PT_OPT_GRID_FIT 0, the default): one timed
+// launch of n_passes passes per candidate — the class the camera needs, the default class when that is smaller, and up to two
+// classes wider while the launch's own far-ray tally says such rays matter and a wider class keeps winning — and the fastest
+// stays.  PT_OPT_GRID_FIT 1: the class the camera needs, unmeasured (no launches here).
+int tune_grid_to_view(pt_ctx* c, uint32_t n_passes, bool* launched) {
+  *launched = false;
+  if (!c->have_grid || !c->have_params || c->captured || c->h_geom.empty()) return PT_OK;
+  bool grid_tried = c->geom_policy == PT_GEOM_GRID;
+  if (c->geom_policy == PT_GEOM_AUTO)
+    for (int k = 0; k < c->n_trials; k++) grid_tried = grid_tried || c->trial_paths[k] == PT_GEOM_GRID;
+  if (!grid_tried) return PT_OK;
+#ifdef PT_DEV_KNOBS
+  if (getenv("PT_GRID_DNEAR")) return PT_OK;
+#endif
+  const double need = view_need_factor(c);
+  if (need <= 0.0) return PT_OK;
+  auto at = [&](double f) { return std::fabs(f - (double)c->grid.near_factor) < 1e-6; };
+  if (c->grid_fit_mode == 1 || n_passes > c->reserved_passes) {  // unmeasured: the class the camera needs
+    return at(need) ? PT_OK : rebuild_grid(c, need, false);
+  }
+  // one timed launch through the grid walk on the grid in place: kernel time from the launch's events, far share from its tallies
+  const int policy_kept = c->geom_policy;
+  struct Probe { double factor, ms, far_share; };
+  std::vector<Probe> probes;
+  auto measure = [&](double f, bool cold) -> int {
+    if (!at(f)) { int rc = rebuild_grid(c, f, false); if (rc != PT_OK) return rc; }
+    if (!c->have_grid || !at(f)) return PT_OK;  // (no grid for that class: not a candidate)
+    c->geom_policy = PT_GEOM_GRID;
+    int rc = PT_OK;
+    for (int k = cold ? 0 : 1; k < 2 && rc == PT_OK; k++) {  // (the very first launch also loads code and settles the tile order: not timed)
+      unsigned long long before[PT_CTR_SCRATCH], after[PT_CTR_SCRATCH];
+      rc = hipStreamSynchronize(c->stream) == hipSuccess ? fold_events(c) : PT_ERR_HIP;
+      if (rc != PT_OK) break;
+      const double ms0 = c->kernel_ms;
+      if (hipMemcpy(before, c->d_counters, sizeof before, hipMemcpyDeviceToHost) != hipSuccess) { rc = PT_ERR_HIP; break; }
+      rc = pt_render_passes(c, n_passes);
+      if (rc != PT_OK) break;
+      rc = hipStreamSynchronize(c->stream) == hipSuccess ? fold_events(c) : PT_ERR_HIP;
+      if (rc != PT_OK) break;
+      if (hipMemcpy(after, c->d_counters, sizeof after, hipMemcpyDeviceToHost) != hipSuccess) { rc = PT_ERR_HIP; break; }
+      if (k == 1) {
+        const double seg = (double)(after[PT_CTR_SEGMENTS] - before[PT_CTR_SEGMENTS]);
+        probes.push_back({f, c->kernel_ms - ms0, seg > 0 ? (double)(after[PT_CTR_FAR_RAYS] - before[PT_CTR_FAR_RAYS]) / seg : 0.0});
+      }
+    }
+    c->geom_policy = policy_kept;
+    *launched = true;
+    return rc == PT_ERR_HIP ? fail(c, PT_ERR_HIP, "pt_tune: a HIP call failed while timing a grid class") : rc;
+  };
+  // (a few passes are enough to rank the classes: the launches compared differ only in the grid they walk)
+  n_passes = n_passes < 4u ? n_passes : 4u;
+  int rc = measure(need, true);
+  if (rc != PT_OK) return rc;
+  if (need < kDefaultNearFactor) { rc = measure(kDefaultNearFactor, false); if (rc != PT_OK) return rc; }
+  auto best = [&]() { size_t b = 0; for (size_t k = 1; k < probes.size(); k++) if (probes[k].ms < probes[b].ms) b = k; return b; };
+  for (int widened = 0; widened < 2 && !probes.empty(); widened++) {
+    const Probe& b = probes[best()];
+    if (b.far_share < 2e-5) break;  // (practically no ray takes the far path: a wider class only adds copies)
+    double next = 0.0;
+    for (double f : kNearFactors) {
+      bool seen = false;
+      for (const Probe& q : probes) seen = seen || std::fabs(q.factor - f) < 1e-6;
+      if (f > b.factor + 1e-6 && !seen) { next = f; break; }
+    }
+    if (next == 0.0) break;
+    const size_t n_before = probes.size();
+    rc = measure(next, false);
+    if (rc != PT_OK) return rc;
+    if (probes.size() == n_before || probes[best()].factor != next) break;  // (no grid for it, or not faster: stop widening)
+  }
+  if (probes.empty()) return PT_OK;
+  const double keep = probes[best()].factor;
+  return at(keep) ? PT_OK : rebuild_grid(c, keep, false);
 }
 
 } // namespace
@@ -1948,11 +2042,13 @@ PT_API int pt_grid_fit(pt_ctx* c) {
 
 PT_API int pt_tune(pt_ctx* c, uint32_t n_passes) {
   if (!c || n_passes == 0) return fail(c, PT_ERR_INVALID, "pt_tune: bad argument");
+  bool launched = false;
   if (c->have_spheres) {
-    int rc = fit_grid_to_view(c, 2);
+    int rc = tune_grid_to_view(c, n_passes, &launched);
     if (rc != PT_OK) return rc;
   }
-  if (c->geom_policy != PT_GEOM_AUTO || !c->have_spheres || c->n_trials < 2) return PT_OK; // nothing to decide
+  if (c->geom_policy != PT_GEOM_AUTO || !c->have_spheres || c->n_trials < 2) // no path to decide
+    return launched ? pt_reset_accum(c) : PT_OK;
   c->geom_tuned = 0;
   c->trial_state = 0;
   for (int k = 0; k < 1 + c->n_trials; k++) {

@@ -185,6 +185,8 @@ __device__ __forceinline__ void shade_segment(const PtKernelArgs& A, Path& p, co
     sample++;
     if (sample >= A.spp) {
       tally.flag(PT_REG_SHADE_ITEM_STORE);
+      // (a plain store: the non-temporal form — global_store_dwordx4 ... nt — measured no time change and MORE written traffic,
+      // config 5 WRITE_SIZE 0.87 -> 1.37 GiB per 16-pass launch against 0.53 GB of slab: profiles/r06_ab_runs.txt)
       float4 outv = make_float4(sum.x, sum.y, sum.z, (float)A.spp);
       reinterpret_cast<float4*>(A.slab)[slab_index] = outv;
       if (item_tile != 0xffffffffu) atomicMax(&A.tile_cost[item_tile], item_segs);

@@ -83,6 +83,10 @@ __device__ __forceinline__ void pt_trace_body(const PtKernelArgs& A) {
       // grid: pt_grid_walk.hpp) is looked at by the whole wave, 64 spheres at a time, like the rays of
       // tail mode, where the list is long (the kernels whose entries do not fit the LDS: thousands of
       // spheres, 0.3 ms per ray through the literal loop; config 5: 2.3e-5 of the rays, 1.5 % of the time)
+      // (not in the build whose entries are staged in the LDS — scenes of hundreds of spheres: measured in round 6, the hand-over
+      // there takes a far ray of a 1 500-sphere scene from ~18 000 to ~1 500 issue slots, but its code costs config 2, which has
+      // no such ray, +0.5 ... +0.8 %; those scenes are served by a grid class that keeps far rays rare instead — pt_tune measures
+      // the classes, pt_refit_grid follows the camera: profiles/r06_ab_runs.txt)
       if constexpr (S::GRID && S::WALK != 4) {
         const bool handed_over = scan_lane && h.lit_from == 0u;
         const unsigned long long m_h = pt_ballot(handed_over);

@@ -23,6 +23,35 @@ def max_local_rows(height, band_rows, world):
     return max(abi.local_rows(height, band_rows, r, world) for r in range(world))
 
 
+def band_layout(height, band_rows, world):
+    """(pad_rows, perm): every rank sends a buffer of pad_rows rows (its own rows first, zeros behind: the ranks' shares
+    differ by a band when the bands do not divide evenly — 1080 rows in 4-row bands over 8 ranks are 34 bands for six ranks and 33 for two),
+    the collective concatenates them in rank order, and image row y is row perm[y] of that concatenation."""
+    pad_rows = max_local_rows(height, band_rows, world)
+    perm = np.zeros(height, dtype=np.int64)
+    for r in range(world):
+        ys = np.asarray(abi.owned_rows(height, band_rows, r, world), dtype=np.int64)
+        perm[ys] = r * pad_rows + np.arange(len(ys), dtype=np.int64)
+    return pad_rows, perm
+
+
+def assemble_rows(parts, height, band_rows):
+    """The gather for ONE process that drives every rank's context itself (one pt_ctx per GPU, as examples/render_bands.c does
+    from plain C; also how an N-rank run is rehearsed on one device): parts[r] is rank r's (local_rows_or_more, width, 4)
+    tensor; they are laid out exactly as all_gather_into_tensor lays out the ranks' padded buffers (band_layout) and
+    de-interleaved by the same permutation.  Returns the (height, width, 4) frame on parts[0]'s device."""
+    import torch
+
+    world = len(parts)
+    pad_rows, perm = band_layout(height, band_rows, world)
+    width = parts[0].shape[1]
+    recv = torch.zeros((world * pad_rows, width, 4), dtype=parts[0].dtype, device=parts[0].device)
+    for r, part in enumerate(parts):
+        rows = abi.local_rows(height, band_rows, r, world)
+        recv[r * pad_rows: r * pad_rows + rows].copy_(part[:rows])
+    return recv.index_select(0, torch.from_numpy(perm).to(recv.device))
+
+
 def gather_rows(local, height, band_rows, rank, world, group=None):
     """all_gather the per-rank row bands and reassemble the full image.
 
@@ -47,11 +76,7 @@ def gather_rows(local, height, band_rows, rank, world, group=None):
            id(group) if group is not None else 0)
     ent = _GATHER_CACHE.get(key)
     if ent is None:
-        pad_rows = max_local_rows(height, band_rows, world)
-        perm = np.zeros(height, dtype=np.int64)
-        for r in range(world):
-            ys = np.asarray(abi.owned_rows(height, band_rows, r, world), dtype=np.int64)
-            perm[ys] = r * pad_rows + np.arange(len(ys), dtype=np.int64)
+        pad_rows, perm = band_layout(height, band_rows, world)
         ent = (
             pad_rows,
             torch.from_numpy(perm).to(local.device),

@@ -131,10 +131,15 @@ class PathTracer:
         as the reference's estimator, different samples: never bit-comparable with the oracle."""
         self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_RUSSIAN_ROULETTE, int(min_depth)))
 
+    def set_grid_fit(self, unmeasured):
+        """How tune() chooses the grid's margin class: False (default) it times the candidates, True it takes the smallest
+        class that covers the camera without launching anything (PT_OPT_GRID_FIT).  Speed only."""
+        self._check(self.lib.pt_set_option(self._ctx, abi.PT_OPT_GRID_FIT, 1 if unmeasured else 0))
+
     def tune(self, n_passes):
-        """Fit the context to scene and uniforms: the grid is rebuilt for the margin class that covers the camera
-        (speed only), then PT_GEOM_AUTO is settled now (one cold + one untimed launch of n_passes passes per usable
-        path); clears the accumulation."""
+        """Fit the context to scene and uniforms: the grid is rebuilt for the margin class that renders this view fastest
+        (measured: one timed launch of n_passes passes per candidate class; speed only), then PT_GEOM_AUTO is settled now
+        (one cold + one untimed launch of n_passes passes per usable path); clears the accumulation."""
         self._check(self.lib.pt_tune(self._ctx, int(n_passes)))
         if self.accum_tensor is not None:
             self.accum_tensor.zero_()

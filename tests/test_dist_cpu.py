@@ -85,6 +85,34 @@ def test_band_helpers():
     assert ptdist.max_local_rows(5, 8, 2) == 5
 
 
+def test_assemble_rows_is_the_collectives_layout_at_the_eight_rank_shape():
+    """dist.assemble_rows — the gather of ONE process that drives every rank's context (a host like examples/render_bands.c;
+    the one-device rehearsal of an 8-rank run, tools/rehearse_ranks.py) — lays the parts out as all_gather_into_tensor lays out
+    the ranks' padded buffers and de-interleaves with the same permutation (band_layout): 1080 rows in 4-row bands over eight
+    ranks are 34 x 6 / 33 x 2 bands, so two ranks send a band of padding.  Every image row must come back from the rank
+    that owns it, whatever lies in the parts beyond a rank's own rows."""
+    from ray_tracer_webgl_amd import abi, dist as ptdist
+
+    height, width, band, world = 1080, 3, 4, 8
+    shares = [abi.local_rows(height, band, r, world) for r in range(world)]
+    assert shares == [136] * 6 + [132] * 2 and ptdist.band_layout(height, band, world)[0] == 136
+    image = torch.arange(height * width * 4, dtype=torch.float32).reshape(height, width, 4)
+    parts = []
+    for r in range(world):
+        ys = torch.as_tensor(np.asarray(abi.owned_rows(height, band, r, world), dtype=np.int64))
+        part = torch.full((140, width, 4), -1.0)  # (more rows than the rank owns, junk behind them: a caller's buffer may be larger)
+        part[: len(ys)] = image[ys]
+        parts.append(part)
+    assert torch.equal(ptdist.assemble_rows(parts, height, band), image)
+    pad_rows, perm = ptdist.band_layout(height, band, world)
+    assert sorted(perm.tolist()) == sorted(r * pad_rows + l for r in range(world) for l in range(shares[r]))
+    # the degenerate partitions: one rank; more ranks than bands (ranks without a row)
+    assert torch.equal(ptdist.assemble_rows([image], height, band), image)
+    small = image[:5]
+    parts = [small[np.asarray(abi.owned_rows(5, 4, r, 3), dtype=np.int64)] if abi.local_rows(5, 4, r, 3) else torch.zeros((0, width, 4)) for r in range(3)]
+    assert torch.equal(ptdist.assemble_rows(parts, 5, 4), small)
+
+
 def _run_bench(*extra):
     import json
     import subprocess

@@ -1459,9 +1459,9 @@ def test_every_launched_wave_is_resident(which):
 
 def test_tune_fits_the_grid_to_the_view(ora):
     """pt_set_spheres builds the grid for rays that start within 2 s0 of the scene's middle (it does not know the camera);
-    pt_tune, the set-up call that knows scene AND uniforms, rebuilds it for the smallest margin class that covers the camera
-    (pt_api.hip fit_grid_to_view): fewer entries for a camera close by, a grid that still serves a camera far out (whose
-    rays would otherwise all be tested against the whole list).  Speed only — the image is the oracle's either way."""
+    pt_tune, the set-up call that knows scene AND uniforms, rebuilds it — here in its unmeasured mode (PT_OPT_GRID_FIT 1) for
+    the smallest margin class that covers the camera: fewer entries for a camera close by, a grid that still serves a camera
+    far out (whose rays would otherwise all be tested against the whole list).  Speed only — the image is the oracle's either way."""
     from ray_tracer_webgl_amd import _lib
 
     lib = _lib.load()
@@ -1474,6 +1474,7 @@ def test_tune_fits_the_grid_to_the_view(ora):
         ref, seg = ora.render(sc.spheres, sc.params, 2)
         t = PathTracer(96, 54)
         t.set_geometry_path(abi.PT_GEOM_GRID)
+        t.set_grid_fit(True)  # the class the camera needs, unmeasured (the measured choice: test_tune_measures_the_margin_class)
         t.set_spheres(sc.spheres)
         t.set_params(sc.params)
         t.reserve_passes(2)
@@ -1573,17 +1574,71 @@ def test_a_camera_that_flies_out_of_the_fitted_region_keeps_a_grid_that_serves_i
         shares[policy] = far_share
         print("policy", policy, "grid factors", factors, "far-ray share per frame", ["%.4f" % x for x in far_share])
         if policy:
-            # as built (3 s0) -> tightened to 2.5 after LOOSE_FRAMES frames inside -> refitted on the way out exactly when the
-            # camera needed a wider class, never before -> tightened again on the way back in
+            # as built (3 s0: a refit never goes below the default class, whether a tighter one pays is pt_tune's measurement) ->
+            # refitted on the way out exactly when the camera needed a wider class, never before -> tightened again on the
+            # way back in, after LOOSE_FRAMES frames on a grid looser than needed
             out = factors[:ticks]
-            assert set(out) == {2.5, 3.0, 4.0, 5.5, 8.0} and out[:3] == [3.0] * 3 and out[3] == 2.5 and out[3:] == sorted(out[3:]), out
-            assert factors[-1] < 8.0 and loop.grid_refits == len([1 for a, b in zip([3.0] + factors, factors) if a != b]) >= 6, (factors, loop.grid_refits)
+            assert set(out) == {3.0, 4.0, 5.5, 8.0} and out == sorted(out), out
+            assert factors[-1] < 8.0 and loop.grid_refits == len([1 for a, b in zip([3.0] + factors, factors) if a != b]) >= 4, (factors, loop.grid_refits)
             assert max(far_share) < 0.01, far_share
         else:
             assert factors == [3.0] * ticks and loop.grid_refits == 0 and loop.tracer.grid_fit() == 1
         loop.close()
     # the cliff the policy removes: at the far end of the flight the unfitted grid hands the camera's rays to the whole list
     assert shares[False][ticks - 1] > 20 * max(shares[True][ticks - 1], 1e-4), (shares[False][ticks - 1], shares[True][ticks - 1])
+
+
+def test_tune_measures_the_margin_class():
+    """The smallest class that covers the CAMERA is a lower bound, not the answer.  A camera inside a 1 500-sphere field that
+    looks across it sees the ground out to the horizon; the rays that bounce off it beyond the near region and come back
+    into the grid's box take the far path, and each costs what hundreds of walked segments cost — the grid for 2.5 s0 (which
+    the camera alone would allow) renders this view about twice as slowly as the default 3 s0.  pt_tune therefore times its
+    candidates: whatever it keeps must be within 15 % of the best of the classes it could have kept, the frame the same bits
+    on all of them, the flag must say "fits", and the far-ray tally must show WHY the tight class loses."""
+    import math
+    import time
+
+    from ray_tracer_webgl_amd import _lib
+    from test_grid import build as grid_build
+
+    sph = scenes.field_spheres(1500)
+    rc, g = grid_build(sph)
+    c0, s0 = g["c0"].astype(np.float64), float(g["s0"])
+    p = scenes._base_params(8, 8)
+    pos = c0 + np.array([0.66, 0.18, 0.73]) / np.linalg.norm([0.66, 0.18, 0.73]) * 0.2 * s0
+    scenes._look_at(_lib.load(), p, 1280, 720, tuple(pos), tuple(c0), 60.0, 0.0, 80.0)
+    sc = scenes.Scene("field", sph, p, 2, "field")
+
+    def run(mode):
+        t = PathTracer(1280, 720)
+        t.set_geometry_path(abi.PT_GEOM_GRID)
+        t.set_spheres(sc.spheres)
+        t.set_params(sc.params)
+        t.reserve_passes(2)
+        if mode == "measured":
+            t.tune(2)
+        elif mode == "need":
+            t.set_grid_fit(True)
+            t.tune(2)
+        ms = []
+        for _ in range(4):
+            t.reset()
+            t.set_params(sc.params)
+            t.render_passes(2)
+            ms.append(t.stats().render_kernel_ms)
+        st = t.stats()
+        out = (min(ms[1:]), float(st.grid_near_factor), st.far_rays / max(st.segments, 1), t.accum(), st.grid_fit_stale)
+        t.close()
+        return out
+
+    built, need, measured = run("built"), run("need"), run("measured")
+    print("as built: %.3f ms at %.1f s0 (far share %.2e); the camera's class: %.3f ms at %.1f s0 (far share %.2e); pt_tune kept %.1f s0: %.3f ms"
+          % (built[0], built[1], built[2], need[0], need[1], need[2], measured[1], measured[0]))
+    assert built[1] == 3.0 and need[1] == 2.5 and measured[1] >= 2.5 and measured[4] == 0
+    assert_bit_equal(need[3], built[3], "2.5 s0 vs 3 s0")
+    assert_bit_equal(measured[3], built[3], "the measured class vs 3 s0")
+    assert measured[0] <= 1.15 * min(built[0], need[0]), (measured[0], built[0], need[0])
+    assert need[2] > 2.0 * built[2] and need[0] > 1.2 * built[0], "this view is the one where the camera's class loses"
 
 
 def test_no_frame_of_the_flight_is_a_cliff():

@@ -200,9 +200,11 @@ def test_config5_as_benchmarked_whole_frame_vs_list_walk_and_oracle(ora):
     t, a = render_scene(sc, tune=8)  # bench.py: pt.tune(min(passes per launch, 8))
     st = t.stats()
     assert st.geometry_path == abi.PT_GEOM_GRID and st.geometry_tuned == 1
-    # the REFIT grid, not the one pt_set_spheres built
-    assert abs(st.grid_near_factor - 2.5) < 1e-6 and st.grid_fit_stale == 0, (st.grid_near_factor, st.grid_fit_stale)
-    assert 0 < st.grid_entries < n_built, (st.grid_entries, n_built)
+    # the grid pt_tune KEPT after timing its candidates (2.5 s0 — what the camera needs — against the 3 s0 pt_set_spheres builds
+    # for): on this view the tight class wins, and then it is the refit grid, with fewer entries, that the frame below walks
+    print("pt_tune kept %.1f s0: %d entries (as built %d)" % (st.grid_near_factor, st.grid_entries, n_built))
+    assert st.grid_near_factor in (2.5, 3.0) and st.grid_fit_stale == 0, (st.grid_near_factor, st.grid_fit_stale)
+    assert (st.grid_entries < n_built) == (st.grid_near_factor == 2.5), (st.grid_entries, n_built)
     assert st.far_rays < 1e-4 * st.segments, (st.far_rays, st.segments)
     t2, b = render_scene(sc, geometry_path=abi.PT_GEOM_SCALAR)
     assert t2.stats().geometry_path == abi.PT_GEOM_SCALAR

@@ -15,6 +15,9 @@ def child():
     else:
         sc = scenes.config2(1920, 1080, spp, n, 50)
     sc.params.time_step = abi.PT_TIME_STEP_DECORRELATED
+    band = os.environ.get("SW_BAND")  # "rows:index:count": one rank's interleaved row bands (bench.py --gpus N, strong scaling)
+    if band:
+        sc.params.band_rows, sc.params.band_index, sc.params.band_count = [int(x) for x in band.split(":")]
     pt = PathTracer(sc.params.width, sc.params.height)
     pt.set_geometry_path(int(os.environ.get("SW_PATH", abi.PT_GEOM_GRID)))
     if os.environ.get("SW_CARRY"): pt.set_carry_lanes(int(os.environ["SW_CARRY"]))
@@ -22,6 +25,9 @@ def child():
     pt.set_spheres(sc.spheres); pt.set_params(sc.params); pt.reserve_passes(n)
     ms = []
     for rep in range(4):
+        if band:  # as in bench.py: every measured launch follows a warm-up of another seed (the tile order it finds)
+            q = sc.params.copy(); q.time = 1000.0 + rep
+            pt.set_params(q); pt.render_passes(n); pt.set_params(sc.params)
         pt.reset(); pt.render_passes(n)
         if not pt.wait(float(os.environ.get("AB_DEADLINE_S", "60"))):  # watchdog: poll with a deadline, never block in the driver
             print("WATCHDOG: launch did not finish", file=sys.stderr, flush=True); os._exit(3)
