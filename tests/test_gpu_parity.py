@@ -1588,6 +1588,53 @@ def test_a_camera_that_flies_out_of_the_fitted_region_keeps_a_grid_that_serves_i
     assert shares[False][ticks - 1] > 20 * max(shares[True][ticks - 1], 1e-4), (shares[False][ticks - 1], shares[True][ticks - 1])
 
 
+def test_a_refit_between_two_replayed_series_recaptures_their_graphs():
+    """pt_render_frames replays hipGraphs whose launches bake the grid's buffers and numbers in.  A refit between two series
+    (the camera has left the fitted region: FrameLoop.frames refits before it replays) must make the next series capture
+    anew — never replay launches that point at the old grid: 9 ticks inside the field, a jump to four scene radii out, 9 more
+    ticks (two groups of four and a single frame per series), canvas and both textures against the same ticks issued one by
+    one (which test_a_camera_that_flies_out_... pins to the oracle's frame loop, refits included)."""
+    import math
+
+    from ray_tracer_webgl_amd.app import FrameLoop
+    from test_grid import build as grid_build
+
+    sph = scenes.field_spheres(1500)
+    rc, g = grid_build(sph)
+    c0, s0 = g["c0"].astype(np.float64), float(g["s0"])
+    w, h = 96, 54
+    loops = []
+    for _ in range(2):
+        lp = FrameLoop(w, h, mode="reference", host_spheres=_host_spheres(sph))
+        lp.tracer.set_geometry_path(abi.PT_GEOM_GRID)
+        lp.state.set_flags(is_paused=False)
+        lp.state.set_quality(1, 8)
+        loops.append(lp)
+    series, ticks = loops
+    direction = np.array([0.66, 0.18, 0.73]) / np.linalg.norm([0.66, 0.18, 0.73])
+    now, factors = 100.0, []
+    for dist_s0 in (0.3, 4.0):
+        pos = c0 + direction * s0 * dist_s0
+        f = (c0 - pos) / np.linalg.norm(c0 - pos)
+        for lp in loops:
+            lp.state.set_camera_origin(pos)
+            lp.state.set_camera_angles(math.degrees(math.atan2(f[2], f[0])), math.degrees(math.asin(f[1])))
+        assert series.frames(9, now, 16.5) == 9
+        for k in range(9):
+            assert ticks.frame(now + 16.5 * k) is True
+        assert np.array_equal(series.canvas, ticks.canvas), "series at %.1f s0" % dist_s0
+        ta, tb = series.textures, ticks.textures
+        assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1], tb[1])
+        st = series.tracer.stats()
+        factors.append(float(st.grid_near_factor))
+        assert st.grid_fit_stale == 0 and st.far_rays < 0.01 * max(st.segments, 1)
+        assert st.segments == ticks.tracer.stats().segments
+        now += 16.5 * 9
+    assert factors == [3.0, 5.5] and series.grid_refits == 1 and ticks.grid_refits == 1, (factors, series.grid_refits)
+    for lp in loops:
+        lp.close()
+
+
 def test_tune_measures_the_margin_class():
     """The smallest class that covers the CAMERA is a lower bound, not the answer.  A camera inside a 1 500-sphere field that
     looks across it sees the ground out to the horizon; the rays that bounce off it beyond the near region and come back
@@ -1689,6 +1736,9 @@ def test_no_frame_of_the_flight_is_a_cliff():
         return (time.perf_counter() - t0) * 1e3
 
     flown, fitted, plain = make(True), make(True), make(False)
+    for loop in (flown, fitted, plain):  # (a context's very first frame loads code and probes its tile order: not the flight's cost)
+        fly(loop, 0)
+        frame_ms(loop)
     rows = []
     for k in range(ticks):
         for loop in (flown, fitted, plain):

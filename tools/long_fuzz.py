@@ -17,6 +17,7 @@ force_small = len(sys.argv) > 3 and sys.argv[3] == "small"  # force the small-li
 used = 0
 bad = 0
 refitted = 0
+classes = {}
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([16, 17, 33, 40, 130, 400, 1500, 4000] if bvh else [1, 2, 5, 9, 17, 40, 130, 400]))
@@ -44,14 +45,38 @@ for seed in range(lo, hi):
             sc.params.camera_origin[0] += float(sc.spheres["center"][0][0]) * 0  # camera stays: distant views
     from ray_tracer_webgl_amd.tracer import PathTracer
     if grid and seed % 2 == 1:
-        # ... with the grid fitted to the scene's camera first (pt_tune: another margin class, another set of entries)
+        # ... with the grid fitted to the scene's camera first (pt_tune: another margin class, another set of entries) — every
+        # fourth scene with the camera PLACED for one of the seven classes in turn and the class taken unmeasured (round 6)
+        if seed % 4 == 3:
+            import ctypes as C
+            import math
+            from ray_tracer_webgl_amd import abi, scenes
+            from test_grid import build as grid_build
+            rc_g, g = grid_build(sc.spheres)
+            if rc_g == 0:
+                want = [2.5, 3.0, 4.0, 5.5, 8.0, 12.0, 16.0][(seed // 4) % 7]
+                c0, s0 = g["c0"].astype(np.float64), float(g["s0"])
+                dvec = rng.normal(size=3)
+                dvec /= np.linalg.norm(dvec)
+                la = abi.PtLookAtIn()
+                la.width, la.height = sc.params.width, sc.params.height
+                la.look_from = abi.d3(*(c0 + dvec * (want / 1.01 - 1.0) * 0.97 * s0))
+                la.look_at = abi.d3(*(c0 + rng.uniform(-0.2, 0.2, 3) * s0))
+                la.vup = abi.d3(0, 1, 0)
+                la.vfov_radians = math.radians(rng.uniform(15, 60))
+                la.focus_distance = max(want - 1.0, 0.5) * s0
+                la.aperture = float(rng.choice([0.0, 0.02 * s0]))
+                assert scenes._lib().pt_camera_look_at(C.byref(la), C.byref(sc.params)) == 0
         t = PathTracer(sc.params.width, sc.params.height)
         t.set_geometry_path(path)
+        if seed % 4 == 3:
+            t.set_grid_fit(True)
         t.set_spheres(sc.spheres)
         t.set_params(sc.params)
         t.reserve_passes(passes)
         before = t.stats().grid_entries
         t.tune(1)
+        classes[round(float(t.stats().grid_near_factor), 1)] = classes.get(round(float(t.stats().grid_near_factor), 1), 0) + 1
         refitted += int(t.stats().grid_entries != before)
         t.set_params(sc.params)
         t.render_passes(passes)
@@ -67,4 +92,4 @@ for seed in range(lo, hi):
     t.close()
     if seed % 50 == 0:
         print("seed", seed, "ok so far, bad =", bad, flush=True)
-print("done", lo, hi, "bad =", bad, "forced path really used:", used, "grids refitted by pt_tune:", refitted)
+print("done", lo, hi, "bad =", bad, "forced path really used:", used, "grids refitted by pt_tune:", refitted, "margin classes walked after pt_tune:", dict(sorted(classes.items())))
