@@ -679,7 +679,9 @@ def main():
         # (profiles/pmc_traffic.json: one record per kernel + config, written by profiles/summarize.py)
         identity = build_identity()
         prior = prior_pmc_record(kernel_name, args.config, args.spp_per_pass, ppl) if world == 1 else None
-        counters = counters_of(prior, avg_ms, identity)
+        # (this run's time of a launch of the record's shape: kernel time per pass x passes per launch — under --steps 20 the timed
+        # region's launches are one of 64 passes and one of 16, whose plain average would not compare with the record's 64)
+        counters = counters_of(prior, ms_per_pass * ppl, identity)
         prior = fresh(prior, identity)  # (a record of another build: no traffic figure either)
         roofline = {
             "kernel": kernel_name,
