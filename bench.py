@@ -611,9 +611,7 @@ def main():
         # (pt_api.hip bind_hierarchy / bind_grid: what fits beside a 1024-thread workgroup's 60 KiB of parked state)
         lds_room = 163776 - 15 * 4 * 1024
         if st.geometry_path == abi.PT_GEOM_GRID:
-            cells_b = 4 * int(st.grid_cells[0]) * int(st.grid_cells[1]) * int(st.grid_cells[2])
-            if cells_b + 16 * int(st.grid_entries) > lds_room:
-                kernel_name += "_cells" if cells_b <= lds_room else "_gmem"
+            kernel_name += {1: "", 2: "_cells", 3: "_gmem"}.get(int(st.grid_kernel_build), "")  # (the library says which build it launches)
         elif st.geometry_path == abi.PT_GEOM_BVH:
             if (2 * int(st.bvh_nodes) + int(st.bvh_slots)) * 16 > lds_room:
                 kernel_name += "_nodes" if int(st.bvh_nodes) * 16 <= lds_room else "_gmem"

@@ -229,6 +229,12 @@ typedef struct PtStats {
   float grid_need_factor;   /* the smallest of those classes that covers the current camera and its lens           */
   uint64_t far_rays;        /* ray segments since the last reset that reached the grid from OUTSIDE its near region and
                                were therefore tested against the whole list (grid walk only; ~0 on a fitted grid)     */
+  uint32_t grid_kernel_build; /* which build of the grid kernel the next launch gets: 1 cell records AND entries staged in the LDS
+                               (pt_trace_kernel_grid), 2 the cell records staged, the entries gathered from L2 (…_grid_cells),
+                               3 nothing staged (…_grid_gmem), 0 no grid.  What fits is staged — except while grid_fit_stale is 1
+                               (the builds that gather hand a far ray to the whole wave: a stale view costs 4 x, not 16 x) and
+                               where pt_tune timed the gathering build faster.  Scheduling only.                       */
+  uint32_t _pad2;
 } PtStats;
 
 typedef struct pt_ctx pt_ctx;
@@ -341,8 +347,9 @@ int pt_set_option(pt_ctx* ctx, int key, int value);
  * covers the camera set by pt_set_params is a lower bound (a camera outside it sends every primary ray down the far path), and
  * whether a class at or above it wins depends on where bounce rays start, so the candidates are measured — one timed launch of
  * n_passes passes each: the class the camera needs, the default class when that is smaller, and up to two classes wider while
- * the launch's far-ray tally says such rays matter and the wider class keeps winning (pt_set_option PT_OPT_GRID_FIT 1: no
- * launches, the class the camera needs).  Speed only, the image does not depend on it; skipped once a launch has been captured
+ * the launch's far-ray tally says such rays matter and the wider class keeps winning; then, on scenes whose staged entries
+ * take more than 16 KB of the LDS, the build that gathers its entries from L2 against the LDS-staged one (PtStats.grid_kernel_build)
+ * (pt_set_option PT_OPT_GRID_FIT 1: no launches, the class the camera needs).  Speed only, the image does not depend on it; skipped once a launch has been captured
  * into a caller's hipGraph.  (ii) Settles PT_GEOM_AUTO now
  * instead of lazily: renders n_passes passes with the current scene
  * and uniforms once cold and once per usable path, keeps the fastest path.  Whenever it has launched anything it clears the

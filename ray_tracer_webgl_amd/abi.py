@@ -149,6 +149,8 @@ class PtStats(C.Structure):
         ("grid_near_factor", C.c_float),
         ("grid_need_factor", C.c_float),
         ("far_rays", C.c_uint64),
+        ("grid_kernel_build", C.c_uint32),  # 1 pt_trace_kernel_grid (all staged in the LDS) / 2 _grid_cells / 3 _grid_gmem / 0 no grid
+        ("_pad2", C.c_uint32),
     ]
 
 

@@ -94,6 +94,7 @@ struct pt_ctx {
   PtMatRec* d_grid_mat = nullptr;
   size_t grid_cell_cap = 0, grid_entry_cap = 0;
   ptgrid::Grid grid;  // host copy of the scalars (the arrays are released after upload)
+  bool grid_cells_build = false;  // pt_tune measured the build that gathers its entries from L2 faster than the LDS-staged one on this scene and view
   int grid_fit_mode = 0;  // PT_OPT_GRID_FIT: 0 pt_tune measures the margin classes, 1 it takes the one the camera needs unmeasured
   int count_work = 0; // PT_OPT_COUNT_WORK: launch the measuring twin of the walk kernel
   uint32_t* d_cell_hist = nullptr;           // grid twins: leaf-round lanes per entry run + coherence bins (pt_debug_cell_hist)
@@ -333,6 +334,23 @@ double view_need_factor(const pt_ctx* c) {
   return factor;
 }
 int grid_fit_state(const pt_ctx* c);  // (below, beside fit_grid_to_view)
+
+// Which build of the grid kernel the next launch gets (PtStats.grid_kernel_build): 1 = cells AND entries staged in the LDS
+// (pt_trace_kernel_grid), 2 = the cell records staged, the entries gathered from L2 (…_grid_cells), 3 = nothing staged (…_grid_gmem),
+// 0 = no grid.  What fits goes into the LDS — with two exceptions (round 6).  (i) A camera OUTSIDE the near region (grid_fit_state 1:
+// the host has not refitted yet) turns every primary ray into a far ray, and the LDS-staged build runs a far ray through the literal
+// loop for ONE lane (~12 instructions per sphere of the list), while its siblings hand it to the whole wave, 64 spheres at a time:
+// the 1 500-sphere field from five scene radii out renders in 2.2-2.9 ms through the cells build against 8-10 ms (and 0.55 ms once
+// refitted).  (ii) pt_tune times both builds on scenes whose entries take a good part of the LDS (fewer workgroups per CU) and
+// keeps the faster (the same field seen from inside: 1.37 against 1.48 ms; config 2, 14 KB of entries: the LDS build by 6 %,
+// not measured there).  Scheduling only: the same entries, the same tests, the same bits.
+int grid_build_kind(const pt_ctx* c, size_t lds_room) {
+  if (!c->have_grid) return 0;
+  const size_t need_cells = PT_GRID_LDS_CELLS((size_t)c->grid.n[0] * c->grid.n[1] * c->grid.n[2]);
+  const size_t need_all = need_cells + (size_t)c->grid.n_entries * 16;
+  if (need_all <= lds_room && !c->grid_cells_build && grid_fit_state(c) != 1) return 1;
+  return need_cells <= lds_room ? 2 : 3;
+}
 
 // LDS a walk kernel may fill with its staged scene: what is left beside a 1024-thread workgroup's parked path state
 constexpr size_t kWalkLdsMax = (size_t)PT_LDS_ENTRIES(PT_MAX_SPHERES_LDS) * 16;
@@ -695,6 +713,7 @@ PT_API int pt_set_spheres(pt_ctx* c, const PtSphere* s, uint32_t n) {
     c->h_mat = mat;
   }
   c->n_spheres = n;
+  c->grid_cells_build = false;  // (a measurement of the previous scene)
   c->epoch++;
   c->scene_gen++;
   c->geom_tuned = 0;  // a new scene: PT_GEOM_AUTO measures again
@@ -1039,11 +1058,12 @@ static size_t bind_grid(pt_ctx* c, bool rr, size_t lds_room, PtKernelArgs& A, co
   A.grid_r2_near = g.r2_near;
   const size_t need_cells = PT_GRID_LDS_CELLS(A.n_cells);
   const size_t need_all = need_cells + (size_t)g.n_entries * 16;
-  if (need_all <= lds_room) {
+  const int build = grid_build_kind(c, lds_room);
+  if (build == 1) {
     *kfn = c->count_work ? extra_kernel(c->device, PT_X_GRID_COUNT) : PT_PICK(rr, pt_trace_kernel_grid, PT_X_GRID_RR);
     return need_all;
   }
-  if (need_cells <= lds_room) {
+  if (build == 2) {
     *kfn = c->count_work ? extra_kernel(c->device, PT_X_GRID_CELLS_COUNT) : PT_PICK(rr, pt_trace_kernel_grid_cells, PT_X_GRID_CELLS_RR);
     return need_cells;
   }
@@ -1839,6 +1859,7 @@ PT_API int pt_get_stats(pt_ctx* c, PtStats* out) {
     out->grid_near_factor = c->grid.near_factor;
     out->grid_need_factor = (float)view_need_factor(c);
     out->grid_fit_stale = (uint32_t)grid_fit_state(c);
+    out->grid_kernel_build = (uint32_t)grid_build_kind(c, walk_lds_room());
   }
   if (c->have_bvh) {
     out->bvh_nodes = c->bvh_n_nodes;
@@ -2024,7 +2045,20 @@ int tune_grid_to_view(pt_ctx* c, uint32_t n_passes, bool* launched) {
   }
   if (probes.empty()) return PT_OK;
   const double keep = probes[best()].factor;
-  return at(keep) ? PT_OK : rebuild_grid(c, keep, false);
+  const double keep_ms = probes[best()].ms;
+  if (!at(keep)) { rc = rebuild_grid(c, keep, false); if (rc != PT_OK) return rc; }
+  // ... and WHICH BUILD walks it (grid_build_kind): where the staged entries take more than 16 KB of the LDS — fewer workgroups per
+  // CU — the build that gathers them from L2 is timed against the LDS-staged one, and kept when it is at least 2 % faster
+  c->grid_cells_build = false;
+  if (c->have_grid && at(keep) && (size_t)c->grid.n_entries * 16 > (size_t)16384 && grid_build_kind(c, walk_lds_room()) == 1) {
+    c->grid_cells_build = true;
+    const size_t n_before = probes.size();
+    rc = measure(keep, true);  // (cold first: another kernel, its code object's first use)
+    if (rc != PT_OK) { c->grid_cells_build = false; return rc; }
+    if (probes.size() == n_before || probes.back().ms > 0.98 * keep_ms) c->grid_cells_build = false;
+    c->epoch++;
+  }
+  return PT_OK;
 }
 
 } // namespace
