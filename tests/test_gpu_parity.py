@@ -1411,6 +1411,65 @@ def test_plain_c_animation_matches_the_python_frame_loop(tmp_path):
     loop.close()
 
 
+def test_plain_c_flight_with_a_key_held_follows_the_camera_with_refits(tmp_path):
+    """examples/fly.c: the reference's rAF loop WITH a movement key held (State::update_position, src/state.rs:411-441)
+    on a 1 500-sphere field, from plain C — per tick update_position, update_render_globals, run_setters, then the two
+    lines a host of a large scene adds (pt_grid_fit == 1 -> pt_refit_grid) and webgl::render (pt_render_frame).  Its canvas
+    after 30 ticks of flying backwards out of the scene must be the Python FrameLoop's (same State, same key, same clock;
+    FrameLoop is pinned to the oracle's frame loop, refits included, by the flight test above), it must have refitted as
+    often, and practically none of its segments may have taken the far path; with refits switched off the canvas is the
+    same bytes and the far path's share shows what the two lines are for."""
+    import ctypes as C
+    import re
+    import struct
+    import subprocess
+
+    from ray_tracer_webgl_amd.app import FrameLoop
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples"), "fly"])
+    sph = np.ascontiguousarray(scenes.field_spheres(1500))
+    sc = scenes.config1(128, 72, 1, 8)  # (the file format carries uniforms; fly.c takes only the spheres)
+    scene = str(tmp_path / "field.bin")
+    with open(scene, "wb") as f:
+        f.write(b"PTSC" + struct.pack("<4I", len(sph), C.sizeof(abi.PtSphere), C.sizeof(abi.PtParams), 1))
+        f.write(bytes(sc.params))
+        f.write(sph.tobytes())
+    w, h, ticks, dt = 128, 72, 30, 11500.0
+    runs = {}
+    for refit in (1, 0):
+        out = str(tmp_path / ("fly%d.ppm" % refit))
+        r = subprocess.run([os.path.join(root, "examples", "fly"), out, scene, str(w), str(h), str(ticks), str(refit)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith(out)][-1]
+        m = re.search(r"(\d+) refits, grid for ([\d.]+) scene radii \(the camera needs ([\d.]+), fit flag (\d), kernel build (\d)\), (\d+) segments, (\d+) of them", line)
+        assert m, line
+        header, pix = open(out, "rb").read().split(b"255\n", 1)
+        img = np.frombuffer(pix, dtype=np.uint8).reshape(h, w, 3)[::-1]
+        runs[refit] = (img, int(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(7)))
+        print(line)
+    # the same flight through the Python frame loop
+    small = np.abs(sph["radius"]) < 100.0
+    mid = 0.5 * (sph["center"][small].astype(np.float64).min(0) + sph["center"][small].astype(np.float64).max(0))
+    loop = FrameLoop(w, h, mode="reference", host_spheres=_host_spheres(sph))
+    loop.state.set_flags(is_paused=False)
+    loop.state.set_camera_origin(mid + np.array([6.5, 2.0, 7.25]))
+    loop.state.set_camera_angles(-132.0, -11.5)
+    loop.state.set_keys(abi.KEY_S)
+    for k in range(ticks):
+        assert loop.frame(dt * (k + 1)) is True
+    canvas = loop.canvas[..., :3]
+    st = loop.tracer.stats()
+    img1, refits1, have1, need1, flag1, build1, seg1, far1 = runs[1]
+    img0, refits0, have0, need0, flag0, build0, seg0, far0 = runs[0]
+    assert np.array_equal(img1, canvas) and np.array_equal(img0, canvas)
+    assert refits1 == loop.grid_refits >= 2 and have1 == float(st.grid_near_factor) >= need1 and flag1 == 0 and build1 == 1
+    assert seg1 == seg0 == st.segments and far1 == st.far_rays and far1 < 0.002 * seg1
+    assert refits0 == 0 and have0 == 3.0 and flag0 == 1 and build0 == 2 and far0 > 20 * max(far1, 1)
+    loop.close()
+
+
 @pytest.mark.parametrize("which", ["small-list", "grid"])
 def test_every_launched_wave_is_resident(which):
     """VERDICT r4 #5.  A full-size launch puts `CUs x resident workgroups` on the machine and every one of them must BE
