@@ -346,7 +346,7 @@ int pt_set_option(pt_ctx* ctx, int key, int value);
  * scene's radius of its middle is rebuilt for the margin class that renders THIS view fastest: the smallest class that
  * covers the camera set by pt_set_params is a lower bound (a camera outside it sends every primary ray down the far path), and
  * whether a class at or above it wins depends on where bounce rays start, so the candidates are measured — one timed launch of
- * n_passes passes each: the class the camera needs, the default class when that is smaller, and up to two classes wider while
+ * a few passes each (as many as make ~4 ms, at most four and at most n_passes): the class the camera needs, the default class when that is smaller, and up to two classes wider while
  * the launch's far-ray tally says such rays matter and the wider class keeps winning; then, on scenes whose staged entries
  * take more than 16 KB of the LDS, the build that gathers its entries from L2 against the LDS-staged one (PtStats.grid_kernel_build)
  * (pt_set_option PT_OPT_GRID_FIT 1: no launches, the class the camera needs).  Speed only, the image does not depend on it; skipped once a launch has been captured

@@ -1997,33 +1997,41 @@ int tune_grid_to_view(pt_ctx* c, uint32_t n_passes, bool* launched) {
   const int policy_kept = c->geom_policy;
   struct Probe { double factor, ms, far_share; };
   std::vector<Probe> probes;
+  // How long a timed launch has to be: long enough to rank grids that differ by 2 % (the device's launch-to-launch spread is
+  // ~0.5 %), no longer — pt_tune is part of a first frame.  The COLD launch (code load, tile order: never a measurement) is ONE
+  // pass and doubles as the yardstick: the timed launches get as many passes as make ~4 ms, at most four and at most n_passes
+  // (config 2: 2 passes, configs 3 and 5: 1; round 6's first version timed 4 passes whatever their length: 27 / 90 / 130 ms)
+  const uint32_t n_most = n_passes < 4u ? n_passes : 4u;
+  uint32_t n_timed = n_most;
   auto measure = [&](double f, bool cold) -> int {
     if (!at(f)) { int rc = rebuild_grid(c, f, false); if (rc != PT_OK) return rc; }
     if (!c->have_grid || !at(f)) return PT_OK;  // (no grid for that class: not a candidate)
     c->geom_policy = PT_GEOM_GRID;
     int rc = PT_OK;
-    for (int k = cold ? 0 : 1; k < 2 && rc == PT_OK; k++) {  // (the very first launch also loads code and settles the tile order: not timed)
+    for (int k = cold ? 0 : 1; k < 2 && rc == PT_OK; k++) {
       unsigned long long before[PT_CTR_SCRATCH], after[PT_CTR_SCRATCH];
       rc = hipStreamSynchronize(c->stream) == hipSuccess ? fold_events(c) : PT_ERR_HIP;
       if (rc != PT_OK) break;
       const double ms0 = c->kernel_ms;
       if (hipMemcpy(before, c->d_counters, sizeof before, hipMemcpyDeviceToHost) != hipSuccess) { rc = PT_ERR_HIP; break; }
-      rc = pt_render_passes(c, n_passes);
+      rc = pt_render_passes(c, k == 0 ? 1u : n_timed);
       if (rc != PT_OK) break;
       rc = hipStreamSynchronize(c->stream) == hipSuccess ? fold_events(c) : PT_ERR_HIP;
       if (rc != PT_OK) break;
       if (hipMemcpy(after, c->d_counters, sizeof after, hipMemcpyDeviceToHost) != hipSuccess) { rc = PT_ERR_HIP; break; }
-      if (k == 1) {
+      const double ms = c->kernel_ms - ms0;
+      if (k == 0 && probes.empty()) {  // the yardstick (an over-estimate: it carries the code load — so the timed launches come out shorter, never longer)
+        const double want = ms > 0.0 ? std::ceil(4.0 / ms) : (double)n_most;
+        n_timed = want < 1.0 ? 1u : (want > (double)n_most ? n_most : (uint32_t)want);
+      } else if (k == 1) {
         const double seg = (double)(after[PT_CTR_SEGMENTS] - before[PT_CTR_SEGMENTS]);
-        probes.push_back({f, c->kernel_ms - ms0, seg > 0 ? (double)(after[PT_CTR_FAR_RAYS] - before[PT_CTR_FAR_RAYS]) / seg : 0.0});
+        probes.push_back({f, ms, seg > 0 ? (double)(after[PT_CTR_FAR_RAYS] - before[PT_CTR_FAR_RAYS]) / seg : 0.0});
       }
     }
     c->geom_policy = policy_kept;
     *launched = true;
     return rc == PT_ERR_HIP ? fail(c, PT_ERR_HIP, "pt_tune: a HIP call failed while timing a grid class") : rc;
   };
-  // (a few passes are enough to rank the classes: the launches compared differ only in the grid they walk)
-  n_passes = n_passes < 4u ? n_passes : 4u;
   int rc = measure(need, true);
   if (rc != PT_OK) return rc;
   if (need < kDefaultNearFactor) { rc = measure(kDefaultNearFactor, false); if (rc != PT_OK) return rc; }
