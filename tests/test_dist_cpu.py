@@ -297,3 +297,29 @@ def test_a_counter_record_of_another_build_is_refused():
     for r in doc["records"]:
         c = bench.counters_of(r, r.get("kernel_ms"), ident)
         assert c["stale"] == (r.get("csrc_sha256") != ident["csrc_sha256"])
+
+
+def test_the_committed_bench_lines_and_counter_records_belong_to_this_build():
+    """The evidence committed under profiles/ for this round — the bench lines (`r06_bench_config*.json`, the driver-flags line) and
+    every record of `pmc_traffic.json` — was collected on the sources in this tree: each names the sha256 of the kernel and host
+    sources it ran on (`build.csrc_sha256`, `_lib.build_identity`), the lines carry their kernel's counter record un-refused
+    (`counters.stale` false) and a true digest verdict.  A later change to `csrc/` or `include/ptrace*.h` makes this fail until the
+    evidence is collected again (`profiles/collect.sh`, `profiles/summarize.py --merge`): that is its purpose.  CPU only."""
+    import json
+
+    from ray_tracer_webgl_amd import _lib
+
+    ident = _lib.build_identity()["csrc_sha256"]
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert {str(r["config"]) for r in doc["records"]} == {"2", "3", "4", "5", "default"}
+    for r in doc["records"]:
+        assert r.get("csrc_sha256") == ident, "the counter record of config %s was collected on another build" % r["config"]
+    for name in ("config2", "config3", "config4", "config5", "configdefault", "driver_flags"):
+        path = os.path.join(ROOT, "profiles", "r06_bench_%s.json" % name)
+        d = json.loads([ln for ln in open(path) if ln.startswith("{")][-1])
+        assert d["build"]["csrc_sha256"] == ident, name
+        c = d["roofline"]["counters"]
+        assert c and c["stale"] is False and c["record_csrc_sha256"] == ident and c["valu_issue_frac"] > 0, name
+        assert 0.9 < c["prior_over_this_run_kernel_ms"] < 1.1, (name, c["prior_over_this_run_kernel_ms"])
+        if name != "configdefault":
+            assert d["gather_matches_single_gpu"] is True and d["gather_check"]["segments_match"] is True, name
